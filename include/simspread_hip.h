@@ -1,0 +1,189 @@
+/*
+ * simspread_hip.h -- C ABI of libsimspread_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the SimSpread.jl hot path
+ *     featurize -> construct -> spread -> predict -> clean!
+ * The reference (cvigilv/SimSpread.jl, pure Julia) has no FFI of its own; its
+ * boundary is the method table exported at src/SimSpread.jl:21-56.  Each entry
+ * point below names the reference method it stands behind (file:line under the
+ * reference tree).  Julia binds these with `ccall` (see INTEGRATION.md and
+ * julia/SimSpreadHIP.jl), this repository's Python mirror binds them with ctypes.
+ *
+ * Conventions
+ *   - plain C types only; no C++/torch types cross this boundary;
+ *   - every function returns SS_OK (0) or a negative SS_E* code and never throws or
+ *     aborts; ss_last_error() returns a thread-local message for the last failure;
+ *   - one process drives one GPU (ss_init(device)); multi-GPU = one process per GPU,
+ *     rows/folds sharded by the host layer, RCCL only for the final score gather;
+ *   - `mem` says where caller buffers live: SS_MEM_HOST (copied during the call) or
+ *     SS_MEM_DEVICE (used in place, e.g. a torch tensor's data_ptr()); the caller
+ *     keeps ownership of every buffer it passes; the library owns what is behind
+ *     the opaque handles;
+ *   - CSR inputs: int64 row pointers, int32 column indices, `index_base` 0 or 1
+ *     (Julia's SparseMatrixCSC is the 1-based CSR of the transpose), column
+ *     indices sorted within each row; a NULL value pointer means "all ones";
+ *     explicitly stored zeros are dropped (degree = number of NON-ZEROS,
+ *     src/graphs.jl:9-11);
+ *   - dense inputs are column-major with a leading dimension, like Julia arrays;
+ *   - score blocks are written in the layout the caller asks for:
+ *       SS_LAYOUT_ROWMAJOR  (r,t) at out[r*ld + t]   (numpy C order; native, no extra pass)
+ *       SS_LAYOUT_COLMAJOR  (r,t) at out[r + t*ld]   (Julia Matrix; one device transpose).
+ */
+#ifndef SIMSPREAD_HIP_H
+#define SIMSPREAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_VERSION 100 /* 0.1.0 */
+
+enum {
+  SS_OK = 0,
+  SS_EINVAL = -1,       /* bad argument / shape / unsorted or out-of-range indices */
+  SS_ENOMEM = -2,       /* device or host allocation failed */
+  SS_EHIP = -3,         /* a HIP runtime call failed (message has the HIP error string) */
+  SS_ENODEV = -4,       /* no usable gfx950 device / ss_init not called */
+  SS_EUNSUPPORTED = -5  /* valid request this build cannot serve (e.g. nnz >= 2^31) */
+};
+
+enum { SS_MEM_HOST = 0, SS_MEM_DEVICE = 1 };
+enum { SS_ROWS_QUERY = 0, SS_ROWS_SOURCE = 1 };
+enum { SS_LAYOUT_ROWMAJOR = 0, SS_LAYOUT_COLMAJOR = 1 };
+
+typedef struct ss_graph ss_graph; /* tri-partite query/source/feature/target graph, device resident */
+typedef struct ss_spmat ss_spmat; /* one sparse operand W of F = W*R, device resident            */
+
+/* ---------------------------------------------------------------- runtime ---- */
+int ss_version(void);
+const char* ss_last_error(void);
+int ss_device_count(void);
+/* Select the GPU this process drives and create the library's stream.  Replaces the
+ * reference's `GPU::Bool` switch (src/core.jl:402,404,446,448). */
+int ss_init(int device);
+int ss_shutdown(void);
+int ss_synchronize(void);
+/* Timings of the last predict/spmm call, milliseconds, measured with hipEvents on the
+ * library stream: ms[0] whole call on device, [1] transfer stage (stage 1), [2] W*R SpMM
+ * (stage 2), [3] epilogues/transposes, [4] host->device, [5] device->host,
+ * [6] number of SpMM launches, [7] number of stage-1 launches.  Writes min(n,8) values. */
+int ss_timing_last(double* ms, int n);
+
+/* ------------------------------------------------------- cutoff / k / spread -- */
+/* cutoff(X, alpha, weighted): out = x >= alpha ? (weighted ? x : 1) : 0, element-wise
+ * (src/core.jl:37-43,55-60; `>=` inclusive per test/runtests.jl:46-47).  Also the value
+ * part of featurize (src/core.jl:106-112).  rows x cols, column-major, ld >= rows. */
+int ss_cutoff_f32(const float* X, int64_t rows, int64_t cols, int64_t ld, float alpha,
+                  int weighted, float* out, int64_t ldo, int mem);
+int ss_cutoff_f64(const double* X, int64_t rows, int64_t cols, int64_t ld, double alpha,
+                  int weighted, double* out, int64_t ldo, int mem);
+/* k(G): number of non-zeros in every row (src/graphs.jl:9-11). */
+int ss_row_degree_f32(const float* G, int64_t rows, int64_t cols, int64_t ld, int64_t* deg, int mem);
+int ss_row_degree_f64(const double* G, int64_t rows, int64_t cols, int64_t ld, int64_t* deg, int mem);
+/* spread(G): W[i,j] = G[i,j] / k(i), rows of degree 0 give 0 (src/core.jl:365-371). */
+int ss_spread_f32(const float* G, int64_t rows, int64_t cols, int64_t ld, float* W, int64_t ldw, int mem);
+int ss_spread_f64(const double* G, int64_t rows, int64_t cols, int64_t ld, double* W, int64_t ldw, int mem);
+
+/* ------------------------------------------------------------ graph handles --- */
+/* construct(...) (src/core.jl:148-201,217-276,294-296,308-337): instead of the dense
+ * N x N block matrices A and B the handle keeps the three non-zero blocks
+ *     Xq = A[queries, features]  (nq x nf)    Xs = A[sources, features]  (ns x nf)
+ *     Ys = A[sources, targets]   (ns x nt)
+ * as CSR on the device together with their transposes and the count degrees kf, ks, kt
+ * of B (spread, src/core.jl:365-371).  nq may be 0 (3-layer graph of src/core.jl:308-337). */
+int ss_graph_create_csr_f32(int64_t nq, int64_t ns, int64_t nf, int64_t nt,
+                            const int64_t* xq_ptr, const int32_t* xq_idx, const float* xq_val,
+                            const int64_t* xs_ptr, const int32_t* xs_idx, const float* xs_val,
+                            const int64_t* ys_ptr, const int32_t* ys_idx, const float* ys_val,
+                            int index_base, int mem, ss_graph** out);
+int ss_graph_create_csr_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt,
+                            const int64_t* xq_ptr, const int32_t* xq_idx, const double* xq_val,
+                            const int64_t* xs_ptr, const int32_t* xs_idx, const double* xs_val,
+                            const int64_t* ys_ptr, const int32_t* ys_idx, const double* ys_val,
+                            int index_base, int mem, ss_graph** out);
+/* Same graph from dense column-major blocks; the similarity cutoff of featurize
+ * (src/core.jl:106-112) is applied on the device while the CSR is assembled when
+ * apply_cutoff != 0 (Sq, Ss raw similarities), otherwise non-zeros are kept as they are.
+ * Y (ns x nt) keeps its non-zero values. */
+int ss_graph_create_dense_f32(int64_t nq, int64_t ns, int64_t nf, int64_t nt,
+                              const float* Sq, int64_t ldq, const float* Ss, int64_t lds,
+                              const float* Y, int64_t ldy, int apply_cutoff, float alpha,
+                              int weighted, int mem, ss_graph** out);
+int ss_graph_create_dense_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt,
+                              const double* Sq, int64_t ldq, const double* Ss, int64_t lds,
+                              const double* Y, int64_t ldy, int apply_cutoff, double alpha,
+                              int weighted, int mem, ss_graph** out);
+/* General form for caller-built adjacency matrices: predict accepts ANY named A, B
+ * (src/core.jl:402-425; the reference's own test passes hand-written 9 x 9 matrices,
+ * test/runtests.jl:120-158).  With n nodes, the caller passes
+ *     L  = A[rows of y, :]        (nr x n)   the rows of A that are asked for
+ *     Bm = B                      (n  x n)   the graph spread() normalises
+ *     Wt = (B[:, cols of y])'     (nc x n)   the columns of B that are asked for, transposed
+ * and ss_predict_*(g, SS_ROWS_QUERY, 0, nr, ...) returns the nr x nc block of A * spread(B)^2.
+ * Degrees are the row non-zero counts of B.  SS_ROWS_SOURCE / leave-one-out do not apply. */
+int ss_graph_create_general_f32(int64_t n, int64_t nr, int64_t nc,
+                                const int64_t* l_ptr, const int32_t* l_idx, const float* l_val,
+                                const int64_t* b_ptr, const int32_t* b_idx, const float* b_val,
+                                const int64_t* w_ptr, const int32_t* w_idx, const float* w_val,
+                                int index_base, int mem, ss_graph** out);
+int ss_graph_create_general_f64(int64_t n, int64_t nr, int64_t nc,
+                                const int64_t* l_ptr, const int32_t* l_idx, const double* l_val,
+                                const int64_t* b_ptr, const int32_t* b_idx, const double* b_val,
+                                const int64_t* w_ptr, const int32_t* w_idx, const double* w_val,
+                                int index_base, int mem, ss_graph** out);
+int ss_graph_destroy(ss_graph* g);
+/* sizes[0..6] = nq, ns, nf, nt, nnz(Xq), nnz(Xs), nnz(Ys) after dropping stored zeros. */
+int ss_graph_info(const ss_graph* g, int64_t sizes[7]);
+/* Count degrees of the query-free graph B: kf[nf], ks[ns], kt[nt] (host buffers; any may be NULL). */
+int ss_graph_degrees(const ss_graph* g, int64_t* kf, int64_t* ks, int64_t* kt);
+
+/* ------------------------------------------------------------------ predict --- */
+/* predict((A,B), y) / predict(A,B,y) / predict(A, ytrain) (src/core.jl:402-425,446-466):
+ * the block of F = A * spread(B)^2 for rows [row_begin,row_end) of the query nodes
+ * (SS_ROWS_QUERY) or of the source nodes (SS_ROWS_SOURCE; feature path + target path,
+ * which is also what the 3-layer predict(A, ytrain) returns) and all nt targets.
+ * clean != 0 fuses clean! (src/core.jl:478-484): column t becomes -99 when target t
+ * has no edge in A.  out holds (row_end-row_begin) x nt scores in `layout`. */
+int ss_predict_f32(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean,
+                   float* out, int64_t ld, int layout, int mem);
+int ss_predict_f64(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean,
+                   double* out, int64_t ld, int layout, int mem);
+/* Leave-one-out cross-validation: row i of the result is
+ *   predict(construct(y, X, [source_i]), y[[source_i], :])   (+ clean! when clean != 0)
+ * for i in [i_begin, i_end), i.e. construct's fold form (src/core.jl:148-201) with
+ * one query per fold, computed from the resident graph by rank-1 degree corrections
+ * instead of rebuilding a graph per fold.  Needs a graph with nq == 0 and ns == nf whose
+ * feature column j is the one named after source j (the column construct drops,
+ * src/core.jl:152).  Folds are independent: shard [i_begin,i_end) across processes. */
+int ss_predict_loo_f32(ss_graph* g, int64_t i_begin, int64_t i_end, int clean,
+                       float* out, int64_t ld, int layout, int mem);
+int ss_predict_loo_f64(ss_graph* g, int64_t i_begin, int64_t i_end, int clean,
+                       double* out, int64_t ld, int layout, int mem);
+
+/* -------------------------------------------------------------- raw W*R SpMM --- */
+/* The resource-spreading product F = W * R on its own (kernel unit tests and the
+ * roofline benchmark; inside predict W = Ys' and R = the transfer block, src/core.jl:413).
+ * W: rows x cols CSR.  R: cols x B dense, F: rows x B dense.
+ *   *_layout == SS_LAYOUT_ROWMAJOR : R(k,b) at R[k*ldr + b], F(m,b) at F[m*ldf + b]
+ *   *_layout == SS_LAYOUT_COLMAJOR : R(k,b) at R[k + b*ldr], F(m,b) at F[m + b*ldf]
+ * B <= 64 with row-major operands takes the HBM-bound CSR kernel; wider B takes the
+ * LDS-tiled kernel (natively column-major; other layouts pay one transpose). */
+int ss_spmat_create_csr_f32(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx,
+                            const float* val, int index_base, int mem, ss_spmat** out);
+int ss_spmat_create_csr_f64(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx,
+                            const double* val, int index_base, int mem, ss_spmat** out);
+int ss_spmat_destroy(ss_spmat* w);
+int ss_spmm_f32(ss_spmat* w, const float* R, int64_t B, int64_t ldr, int r_layout,
+                float* F, int64_t ldf, int f_layout, int mem);
+int ss_spmm_f64(ss_spmat* w, const double* R, int64_t B, int64_t ldr, int r_layout,
+                double* F, int64_t ldf, int f_layout, int mem);
+/* Algorithmic bytes of one ss_spmm call (SURVEY.md section 8d:
+ * nnz*(vb+4) + (rows+1)*4 + cols*B*vb + rows*B*vb) and its flops 2*nnz*B. */
+int ss_spmat_cost(const ss_spmat* w, int64_t B, double* bytes, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMSPREAD_HIP_H */

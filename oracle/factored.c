@@ -1,0 +1,114 @@
+/*
+ * CPU restatement (C, fp64, OpenMP) of the factored SimSpread prediction -- TEST INFRASTRUCTURE.
+ *
+ * Used only as a checker (tests/) and as the timed "cpu_baseline" of bench.py (kind "port": Julia is
+ * not installed here, so the reference itself cannot be timed).  It restates what the reference
+ * computes on the path spread -> predict (src/core.jl:365-371,402-423: F = A * spread(B)^2, of which
+ * the queries x targets block is returned, src/core.jl:421) in the algebraically equal sparse form
+ *     Yq = (Xq D_f^-1) Xs' (D_s^-1 Ys),   degrees = non-zero COUNTS (src/graphs.jl:9-11),
+ *     1/0 -> 0 (src/core.jl:367-368),
+ * which tests/test_oracle.py proves equal to the literal dense restatement in simspread_oracle.py
+ * (itself pinned by the reference's known-answer tests).  The product package never links this.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+  int64_t rows, cols;
+  int64_t* ptr;
+  int32_t* idx;
+  double* val;
+} csr_t;
+
+static int csr_transpose(const int64_t rows, const int64_t cols, const int64_t* ptr, const int32_t* idx,
+                         const double* val, csr_t* out) {
+  const int64_t nnz = ptr[rows];
+  out->rows = cols;
+  out->cols = rows;
+  out->ptr = (int64_t*)calloc((size_t)cols + 2, sizeof(int64_t));
+  out->idx = (int32_t*)malloc((size_t)(nnz ? nnz : 1) * sizeof(int32_t));
+  out->val = (double*)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+  if (!out->ptr || !out->idx || !out->val) return -1;
+  for (int64_t x = 0; x < nnz; ++x)
+    if (val[x] != 0.0) out->ptr[idx[x] + 2]++;
+  for (int64_t c = 0; c < cols; ++c) out->ptr[c + 2] += out->ptr[c + 1];
+  for (int64_t r = 0; r < rows; ++r)
+    for (int64_t x = ptr[r]; x < ptr[r + 1]; ++x)
+      if (val[x] != 0.0) {
+        const int64_t o = out->ptr[idx[x] + 1]++;
+        out->idx[o] = (int32_t)r;
+        out->val[o] = val[x];
+      }
+  return 0;
+}
+
+static void csr_free(csr_t* m) {
+  free(m->ptr);
+  free(m->idx);
+  free(m->val);
+}
+
+static double inv_count(int64_t d) { return d > 0 ? 1.0 / (double)d : 0.0; }
+
+/* Scores of query rows [r0, r1) against all targets; out is row-major (r1-r0) x nt.
+ * Returns 0 on success.  threads <= 0 -> OpenMP default. */
+int oracle_predict_query(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const int64_t* xq_ptr,
+                         const int32_t* xq_idx, const double* xq_val, const int64_t* xs_ptr, const int32_t* xs_idx,
+                         const double* xs_val, const int64_t* ys_ptr, const int32_t* ys_idx, const double* ys_val,
+                         int64_t r0, int64_t r1, double* out, int threads) {
+  (void)nq;
+  csr_t XsT, YsT;
+  if (csr_transpose(ns, nf, xs_ptr, xs_idx, xs_val, &XsT)) return -1;
+  if (csr_transpose(ns, nt, ys_ptr, ys_idx, ys_val, &YsT)) return -1;
+  double* inv_kf = (double*)malloc((size_t)(nf ? nf : 1) * sizeof(double));
+  double* inv_ks = (double*)malloc((size_t)(ns ? ns : 1) * sizeof(double));
+  for (int64_t f = 0; f < nf; ++f) inv_kf[f] = inv_count(XsT.ptr[f + 1] - XsT.ptr[f]);
+  for (int64_t s = 0; s < ns; ++s) {
+    int64_t d = 0;
+    for (int64_t x = xs_ptr[s]; x < xs_ptr[s + 1]; ++x) d += xs_val[x] != 0.0;
+    for (int64_t x = ys_ptr[s]; x < ys_ptr[s + 1]; ++x) d += ys_val[x] != 0.0;
+    inv_ks[s] = inv_count(d);
+  }
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+  {
+    double* v = (double*)malloc((size_t)(ns ? ns : 1) * sizeof(double));
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t q = r0; q < r1; ++q) {
+      memset(v, 0, (size_t)ns * sizeof(double));
+      for (int64_t x = xq_ptr[q]; x < xq_ptr[q + 1]; ++x) {
+        const int32_t f = xq_idx[x];
+        const double c = xq_val[x] * inv_kf[f];
+        if (c == 0.0) continue;
+        for (int64_t z = XsT.ptr[f]; z < XsT.ptr[f + 1]; ++z) v[XsT.idx[z]] += c * XsT.val[z];
+      }
+      for (int64_t s = 0; s < ns; ++s) v[s] *= inv_ks[s];
+      double* o = out + (q - r0) * nt;
+      for (int64_t t = 0; t < nt; ++t) {
+        double acc = 0.0;
+        for (int64_t z = YsT.ptr[t]; z < YsT.ptr[t + 1]; ++z) acc += YsT.val[z] * v[YsT.idx[z]];
+        o[t] = acc;
+      }
+    }
+    free(v);
+  }
+  free(inv_kf);
+  free(inv_ks);
+  csr_free(&XsT);
+  csr_free(&YsT);
+  return 0;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

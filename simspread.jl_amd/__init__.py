@@ -1,0 +1,13 @@
+"""simspread.jl_amd -- MI355X-native SimSpread resource-spreading engine.
+
+The hot path ``featurize -> construct -> spread -> predict -> clean!`` of cvigilv/SimSpread.jl
+(src/core.jl) behind the reference's own function names, computed by hand-written gfx950
+kernels in ``libsimspread_hip.so`` (C ABI: include/simspread_hip.h).  No CPU fallback.
+"""
+from . import _lib
+from ._lib import SimSpreadError, init, timing_last
+from .core import (NamedMatrix, Network, clean, clean_, construct, cutoff, featurize, k, names, predict, spread)
+from .engine import DeviceGraph, DeviceSpMat
+
+__all__ = ["NamedMatrix", "Network", "DeviceGraph", "DeviceSpMat", "SimSpreadError", "init", "timing_last",
+           "k", "cutoff", "featurize", "construct", "spread", "predict", "clean", "clean_", "names"]

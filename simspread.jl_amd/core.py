@@ -1,0 +1,340 @@
+"""Host-side mirror of SimSpread.jl's hot-path API (src/SimSpread.jl:21-56), same names, argument
+meaning and error behaviour, computing on the MI355X through libsimspread_hip.so.
+
+    k, cutoff, featurize, construct (4 methods), spread, predict (3 methods), clean (= clean!)
+
+Julia is not installed where this is built, so this mirror is Python; the Julia binding a
+maintainer would drop into the reference is julia/SimSpreadHIP.jl.
+
+Differences that are deliberate and visible:
+  * ``construct`` returns light ``Network`` objects that keep the blocks Xq/Xs/Ys instead of
+    materialising the dense N x N matrices; ``Network.array`` builds the dense matrix on demand
+    (small graphs only) so code that inspects ``A.array`` / ``names(A, 1)`` keeps working.
+  * ``GPU=`` keyword: accepted and ignored -- this build always runs on the GPU (fp64 by
+    default, like the reference's CPU path; ``precision="f32"`` selects what ``GPU=true`` used).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib as L
+from .engine import DeviceGraph
+
+
+# --------------------------------------------------------------------------- NamedMatrix
+class NamedMatrix:
+    """Matrix + row/column names (stand-in for NamedArrays.NamedMatrix used throughout the reference)."""
+
+    def __init__(self, array, rows: Optional[Sequence] = None, cols: Optional[Sequence] = None):
+        self.array = np.array(array, dtype=np.float64, ndmin=2)
+        r, c = self.array.shape
+        # NamedArrays' default names are "1".."n"
+        self.rows = [str(x) for x in (rows if rows is not None else range(1, r + 1))]
+        self.cols = [str(x) for x in (cols if cols is not None else range(1, c + 1))]
+        if len(self.rows) != r or len(self.cols) != c:
+            raise ValueError("name lists do not match matrix shape")
+        if len(set(self.rows)) != r or len(set(self.cols)) != c:
+            raise ValueError("duplicate names")
+
+    def names(self, dim: int) -> List[str]:
+        return list(self.rows if dim == 1 else self.cols)
+
+    def setnames(self, names: Sequence, dim: int) -> None:
+        names = [str(n) for n in names]
+        if dim == 1:
+            assert len(names) == self.array.shape[0]
+            self.rows = names
+        else:
+            assert len(names) == self.array.shape[1]
+            self.cols = names
+
+    @property
+    def shape(self):
+        return self.array.shape
+
+    def sub(self, rows: Sequence, cols: Sequence) -> "NamedMatrix":
+        ri = {n: i for i, n in enumerate(self.rows)}
+        ci = {n: i for i, n in enumerate(self.cols)}
+        try:
+            r = [ri[str(n)] for n in rows]
+            c = [ci[str(n)] for n in cols]
+        except KeyError as e:
+            raise KeyError(f"name {e} not found") from None
+        return NamedMatrix(self.array[np.ix_(r, c)], [str(n) for n in rows], [str(n) for n in cols])
+
+    def copy(self) -> "NamedMatrix":
+        return NamedMatrix(self.array.copy(), list(self.rows), list(self.cols))
+
+    def __eq__(self, other):  # NamedArrays `==` compares values only
+        if isinstance(other, NamedMatrix):
+            return self.array.shape == other.array.shape and bool((self.array == other.array).all())
+        return NotImplemented
+
+    def __repr__(self):
+        return f"NamedMatrix({self.array.shape[0]}x{self.array.shape[1]})"
+
+
+def names(M, dim: int) -> List[str]:
+    return M.names(dim)
+
+
+# --------------------------------------------------------------------------- k / cutoff / featurize / spread
+def _dev_dtype(precision: str):
+    return {"f64": np.float64, "f32": np.float32}[precision]
+
+
+def k(G, *args):
+    """Node degrees = number of non-zeros per row (src/graphs.jl:9-11).
+
+    k(v) -> count for a vector; k(G) -> (N,1) integer matrix; k(i, G) -> count of (1-based) row i.
+    """
+    if args:  # k(i, G)
+        i, G = G, args[0]
+        return k(np.asarray(G.array if isinstance(G, NamedMatrix) else G)[int(i) - 1, :])
+    a = np.asarray(G.array if isinstance(G, NamedMatrix) else G)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+        vec = True
+    else:
+        vec = False
+    a = np.asfortranarray(a, dtype=np.float64)
+    deg = np.zeros(a.shape[0], np.int64)
+    L.check(L.lib().ss_row_degree_f64(a.ctypes.data, a.shape[0], a.shape[1], max(a.shape[0], 1), deg.ctypes.data,
+                                      L.SS_MEM_HOST))
+    return np.int64(deg[0]) if vec else deg.reshape(-1, 1)
+
+
+def cutoff(x, alpha: float, weighted: bool = False):
+    """x >= alpha ? (weighted ? x : 1.0) : 0.0 (src/core.jl:37-43,55-60)."""
+    if np.ndim(x) == 0:
+        a = np.array([[x]], dtype=np.float64)
+        scalar = True
+    else:
+        a = np.asarray(x, dtype=np.float64)
+        scalar = False
+    shape = a.shape
+    a2 = np.asfortranarray(a.reshape(shape[0], -1))
+    out = np.empty_like(a2, order="F")
+    L.check(L.lib().ss_cutoff_f64(a2.ctypes.data, a2.shape[0], a2.shape[1], max(a2.shape[0], 1), float(alpha),
+                                  1 if weighted else 0, out.ctypes.data, max(a2.shape[0], 1), L.SS_MEM_HOST))
+    return float(out[0, 0]) if scalar else np.ascontiguousarray(out).reshape(shape)
+
+
+def featurize(X: NamedMatrix, alpha: float, weighted: bool = True) -> NamedMatrix:
+    """Similarity cutoff + column rename "f" * name (src/core.jl:106-112)."""
+    out = NamedMatrix(cutoff(X.array, alpha, weighted), list(X.rows), ["f" + c for c in X.cols])
+    return out
+
+
+def spread(G):
+    """Transfer matrix W = G ./ k(G), zero-degree rows -> 0 (src/core.jl:365-371,373,375-380)."""
+    named = isinstance(G, NamedMatrix)
+    a = np.asfortranarray(np.asarray(G.array if named else G, dtype=np.float64))
+    out = np.empty_like(a, order="F")
+    L.check(L.lib().ss_spread_f64(a.ctypes.data, a.shape[0], a.shape[1], max(a.shape[0], 1), out.ctypes.data,
+                                  max(a.shape[0], 1), L.SS_MEM_HOST))
+    out = np.ascontiguousarray(out)
+    return NamedMatrix(out, G.rows, G.cols) if named else out
+
+
+# --------------------------------------------------------------------------- construct
+class Network:
+    """What ``construct`` returns in place of a dense named N x N adjacency matrix.
+
+    ``kind`` is "A" (full graph), "B" (query rows/columns zeroed, src/core.jl:196-198) or
+    "single" (3-layer graph of src/core.jl:308-337).  Node order is [queries; sources; features;
+    targets] (test/runtests.jl:97-98)."""
+
+    def __init__(self, kind, queries, sources, features, targets, Xq, Xs, Ys):
+        self.kind = kind
+        self.queries, self.sources, self.features, self.targets = queries, sources, features, targets
+        self.Xq, self.Xs, self.Ys = Xq, Xs, Ys
+        self._names = list(queries) + list(sources) + list(features) + list(targets)
+        if len(set(self._names)) != len(self._names):
+            raise ValueError("duplicate node names in the network")
+        self._dev = {}
+
+    def names(self, dim: int) -> List[str]:
+        return list(self._names)
+
+    @property
+    def rows(self):
+        return list(self._names)
+
+    @property
+    def cols(self):
+        return list(self._names)
+
+    @property
+    def array(self) -> np.ndarray:
+        nq, ns, nf, nt = len(self.queries), len(self.sources), len(self.features), len(self.targets)
+        n = nq + ns + nf + nt
+        A = np.zeros((n, n))
+        oq, os_, of, ot = 0, nq, nq + ns, nq + ns + nf
+        if self.kind != "B" and nq:
+            A[oq:oq + nq, of:of + nf] = self.Xq
+            A[of:of + nf, oq:oq + nq] = self.Xq.T
+        A[os_:os_ + ns, of:of + nf] = self.Xs
+        A[os_:os_ + ns, ot:ot + nt] = self.Ys
+        A[of:of + nf, os_:os_ + ns] = self.Xs.T
+        A[ot:ot + nt, os_:os_ + ns] = self.Ys.T
+        return A
+
+    def device(self, precision: str = "f64") -> DeviceGraph:
+        if precision not in self._dev:
+            self._dev[precision] = DeviceGraph.from_dense(self.Xq if len(self.queries) else None, self.Xs, self.Ys,
+                                                          alpha=None, dtype=_dev_dtype(precision))
+        return self._dev[precision]
+
+
+def _assert_names_differ(features, sources, msg):
+    # the reference compares the two sorted name vectors element-wise (src/core.jl:156,231,314):
+    # unequal lengths raise DimensionMismatch (unless one side has one element)
+    f, s = sorted(features), sorted(sources)
+    if len(f) != len(s) and len(f) != 1 and len(s) != 1:
+        raise ValueError("DimensionMismatch: arrays could not be broadcast to a common size; "
+                         f"got a dimension with lengths {len(f)} and {len(s)}")
+    n = max(len(f), len(s))
+    ff = f * n if len(f) == 1 else f
+    ss = s * n if len(s) == 1 else s
+    if not all(a != b for a, b in zip(ff, ss)):
+        raise AssertionError(msg)
+
+
+def construct(*args):
+    """construct(y, X, queries) | construct((ytrain,ytest),(Xtrain,Xtest)) |
+    construct(ytrain, ytest, Xtrain, Xtest) | construct(y, X)   (src/core.jl:148-201,217-276,294-296,308-337)."""
+    if len(args) == 3:
+        y, X, queries = args
+        if y.shape[0] != X.shape[0]:
+            raise AssertionError("Labels and features have different number of source nodes")
+        queries = [str(q) for q in queries]
+        qset = set(queries)
+        features = [f for f in X.cols if f.lstrip("f") not in qset]
+        sources = [d for d in X.rows if d not in qset]
+        targets = list(y.cols)
+        _assert_names_differ(features, sources, "Source and Features nodes have the same names!")
+        Xq = X.sub(queries, features).array
+        Xs = X.sub(sources, features).array
+        Ys = y.sub(sources, targets).array
+        A = Network("A", queries, sources, features, targets, Xq, Xs, Ys)
+        B = Network("B", queries, sources, features, targets, Xq, Xs, Ys)
+        B._dev = A._dev
+        return A, B
+    if len(args) == 4:
+        ytrain, ytest, Xtrain, Xtest = args
+        return construct((ytrain, ytest), (Xtrain, Xtest))
+    if len(args) == 2 and isinstance(args[0], tuple):
+        (ytrain, ytest), (Xtrain, Xtest) = args
+        if ytrain.shape[1] != ytest.shape[1]:
+            raise AssertionError("Number of targets between test and training sets doesn't match")
+        if Xtrain.shape[1] != Xtest.shape[1]:
+            raise AssertionError("Number of features between test and training sets doesn't match")
+        features, sources = list(Xtrain.cols), list(ytrain.rows)
+        targets, queries = list(ytrain.cols), list(ytest.rows)
+        _assert_names_differ(features, sources, "Features and drugs have the same names!")
+        A = Network("A", queries, sources, features, targets, Xtest.array, Xtrain.array, ytrain.array)
+        B = Network("B", queries, sources, features, targets, Xtest.array, Xtrain.array, ytrain.array)
+        B._dev = A._dev
+        return A, B
+    if len(args) == 2:
+        y, X = args
+        features, sources, targets = list(X.cols), list(y.rows), list(y.cols)
+        _assert_names_differ(features, sources, "Source and feature nodes have the same names")
+        return Network("single", [], sources, features, targets, np.zeros((0, len(features))), X.array, y.array)
+    raise TypeError("construct: no method matching these arguments")
+
+
+# --------------------------------------------------------------------------- predict / clean!
+def _predict_network(A: Network, y, precision: str) -> NamedMatrix:
+    dev = A.device(precision)
+    qi = {n: i for i, n in enumerate(A.queries)}
+    si = {n: i for i, n in enumerate(A.sources)}
+    ti = {n: i for i, n in enumerate(A.targets)}
+    rows, cols = y.names(1), y.names(2)
+    if not all(c in ti for c in cols) or not all((r in qi) or (r in si) for r in rows):
+        return None  # asks for a block outside [queries|sources] x targets: general path
+    out = np.zeros((len(rows), len(cols)))
+    tcols = [ti[c] for c in cols]
+    q_rows = [(o, qi[r]) for o, r in enumerate(rows) if r in qi]
+    s_rows = [(o, si[r]) for o, r in enumerate(rows) if r not in qi]
+    if q_rows:
+        lo, hi = min(i for _, i in q_rows), max(i for _, i in q_rows) + 1
+        blk = dev.predict("query", lo, hi)
+        out[[o for o, _ in q_rows]] = blk[[i - lo for _, i in q_rows]][:, tcols]
+    if s_rows:
+        lo, hi = min(i for _, i in s_rows), max(i for _, i in s_rows) + 1
+        blk = dev.predict("source", lo, hi)
+        out[[o for o, _ in s_rows]] = blk[[i - lo for _, i in s_rows]][:, tcols]
+    return NamedMatrix(out, rows, cols)
+
+
+def _predict_general(A, B, y, precision: str) -> NamedMatrix:
+    import scipy.sparse as sp
+    An, Bn = A.names(1), B.names(1)
+    Aa, Ba = np.asarray(A.array, dtype=np.float64), np.asarray(B.array, dtype=np.float64)
+    if Aa.shape != Ba.shape or Aa.shape[0] != Aa.shape[1]:
+        raise ValueError("DimensionMismatch: A and B must be square matrices of the same size")
+    ri = {n: i for i, n in enumerate(An)}
+    ci = {n: i for i, n in enumerate(A.names(2))}
+    rows, cols = y.names(1), y.names(2)
+    r = [ri[n] for n in rows]
+    c = [ci[n] for n in cols]
+    dev = DeviceGraph.general(sp.csr_matrix(Aa[r, :]), sp.csr_matrix(Ba), sp.csr_matrix(Ba[:, c].T),
+                              dtype=_dev_dtype(precision))
+    out = dev.predict("query")
+    dev.close()
+    return NamedMatrix(np.asarray(out, dtype=np.float64), rows, cols)
+
+
+def predict(*args, GPU: bool = False, precision: str = "f64") -> NamedMatrix:
+    """predict((A,B), ytest) | predict(A, B, ytest) | predict(A, ytrain)   (src/core.jl:402-425,446-466).
+
+    Returns the block of F = A * spread(B)^2 named by the rows/columns of the last argument, as a
+    NamedMatrix of Float64 (the reference widens GPU results back to Float64, src/core.jl:413)."""
+    if len(args) == 3:
+        A, B, y = args
+    elif len(args) == 2 and isinstance(args[0], tuple):
+        (A, B), y = args
+    elif len(args) == 2:
+        A, y = args
+        B = A  # predict(A, ytrain): W = spread(A)
+    else:
+        raise TypeError("predict: no method matching these arguments")
+    if GPU and precision == "f64":
+        precision = "f32"  # what the reference's GPU=true computed in (src/core.jl:404)
+    network_pair = (isinstance(A, Network) and isinstance(B, Network) and B._dev is A._dev and
+                    (B.kind == "B" or (B is A and not A.queries)))
+    if network_pair:
+        res = _predict_network(A, y, precision)
+        if res is not None:
+            return res
+    return _predict_general(A, B, y, precision)
+
+
+def clean(yhat: NamedMatrix, A, y) -> None:
+    """clean!(yhat, A, y): column t of yhat becomes -99 when target t has degree 0 in A (src/core.jl:478-484)."""
+    tnames = y.names(2)
+    if isinstance(A, Network):
+        ti = {n: i for i, n in enumerate(A.targets)}
+        if all(t in ti for t in tnames):
+            _, _, kt = A.device("f64").degrees()
+            deg = [kt[ti[t]] for t in tnames]
+        else:
+            deg = k(_rows_of(A, tnames)).ravel()
+    else:
+        deg = k(_rows_of(A, tnames)).ravel()
+    ci = {n: i for i, n in enumerate(yhat.cols)}
+    for t, d in zip(tnames, deg):
+        if d == 0:
+            yhat.array[:, ci[t]] = -99.0
+
+
+def _rows_of(A, rownames):
+    idx = {n: i for i, n in enumerate(A.names(1))}
+    return np.asarray(A.array)[[idx[n] for n in rownames], :]
+
+
+clean_ = clean  # Julia's `clean!`

@@ -1,0 +1,773 @@
+// extern "C" surface of libsimspread_hip.so (see include/simspread_hip.h for the contract and the
+// reference methods each entry point stands behind).  Host-side orchestration only: argument
+// checks, staging of caller buffers, the stage-1 / stage-2 launch sequence, event timing.
+#include <cstdlib>
+#include <new>
+
+#include "graph.hpp"
+
+namespace ss {
+
+// ------------------------------------------------------------------ errors / context
+std::string& last_error() {
+  static thread_local std::string msg;
+  return msg;
+}
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+Ctx& ctx() {
+  static Ctx c;
+  return c;
+}
+
+int require_init() {
+  if (!ctx().inited) return fail(SS_ENODEV, "ss_init(device) has not been called (the HIP path has no CPU fallback)");
+  return SS_OK;
+}
+
+void timing_begin_call() {
+  Timing& t = ctx().timing;
+  t.used = 0;
+  t.spans.clear();
+  for (double& e : t.extra) e = 0;
+  t.dirty = true;
+}
+
+int timing_mark(hipEvent_t* ev) {
+  Timing& t = ctx().timing;
+  if (t.used == t.pool.size()) {
+    hipEvent_t e;
+    SS_HIP(hipEventCreate(&e));
+    t.pool.push_back(e);
+  }
+  *ev = t.pool[t.used++];
+  SS_HIP(hipEventRecord(*ev, ctx().stream));
+  return SS_OK;
+}
+
+void timing_span(int stage, hipEvent_t a, hipEvent_t b) { ctx().timing.spans.push_back({stage, a, b}); }
+void timing_count(int stage, double inc) { ctx().timing.extra[stage] += inc; }
+
+static int check_mem(int mem) {
+  if (mem != SS_MEM_HOST && mem != SS_MEM_DEVICE) return fail(SS_EINVAL, "mem must be SS_MEM_HOST or SS_MEM_DEVICE");
+  return SS_OK;
+}
+static int check_layout(int layout) {
+  if (layout != SS_LAYOUT_ROWMAJOR && layout != SS_LAYOUT_COLMAJOR) return fail(SS_EINVAL, "unknown layout");
+  return SS_OK;
+}
+
+// RAII marks: a span of one stage on the stream
+struct StageTimer {
+  int stage;
+  hipEvent_t a = nullptr;
+  bool ok = false;
+  explicit StageTimer(int s) : stage(s) { ok = timing_mark(&a) == SS_OK; }
+  void stop() {
+    hipEvent_t b;
+    if (ok && timing_mark(&b) == SS_OK) timing_span(stage, a, b);
+    ok = false;
+  }
+  ~StageTimer() { stop(); }
+};
+
+// ------------------------------------------------------------------ element-wise entry points
+template <class T>
+static int cutoff_impl(const T* X, int64_t rows, int64_t cols, int64_t ld, T alpha, int weighted, T* out,
+                       int64_t ldo, int mem) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (rows < 0 || cols < 0 || ld < rows || ldo < rows) return fail(SS_EINVAL, "cutoff: bad shape / leading dimension");
+  if (rows * cols == 0) return SS_OK;
+  if (!X || !out) return fail(SS_EINVAL, "cutoff: NULL buffer");
+  hipStream_t st = ctx().stream;
+  if (mem == SS_MEM_DEVICE) {
+    SS_TRY(launch_cutoff<T>(X, rows, cols, ld, alpha, weighted != 0, out, ldo));
+    return SS_OK;
+  }
+  DevBuf<T> din, dout;
+  SS_TRY(din.alloc((size_t)rows * cols));
+  SS_TRY(dout.alloc((size_t)rows * cols));
+  SS_HIP(hipMemcpy2DAsync(din.p, rows * sizeof(T), X, ld * sizeof(T), rows * sizeof(T), cols, hipMemcpyHostToDevice, st));
+  SS_TRY(launch_cutoff<T>(din.p, rows, cols, rows, alpha, weighted != 0, dout.p, rows));
+  SS_HIP(hipMemcpy2DAsync(out, ldo * sizeof(T), dout.p, rows * sizeof(T), rows * sizeof(T), cols, hipMemcpyDeviceToHost, st));
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
+template <class T>
+static int row_degree_impl(const T* G, int64_t rows, int64_t cols, int64_t ld, int64_t* deg, int mem) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (rows < 0 || cols < 0 || ld < rows) return fail(SS_EINVAL, "k: bad shape / leading dimension");
+  if (rows == 0) return SS_OK;
+  if (!deg || (cols > 0 && !G)) return fail(SS_EINVAL, "k: NULL buffer");
+  hipStream_t st = ctx().stream;
+  DevBuf<T> din;
+  const T* src = G;
+  int64_t sld = ld;
+  if (mem == SS_MEM_HOST && cols > 0) {
+    SS_TRY(din.alloc((size_t)rows * cols));
+    SS_HIP(hipMemcpy2DAsync(din.p, rows * sizeof(T), G, ld * sizeof(T), rows * sizeof(T), cols, hipMemcpyHostToDevice, st));
+    src = din.p;
+    sld = rows;
+  }
+  DevBuf<int> d;
+  SS_TRY(d.alloc(rows));
+  SS_TRY(launch_row_degree<T>(src, rows, cols, sld, d.p));
+  std::vector<int> h(rows);
+  SS_HIP(hipMemcpyAsync(h.data(), d.p, rows * sizeof(int), hipMemcpyDeviceToHost, st));
+  SS_HIP(hipStreamSynchronize(st));
+  if (mem == SS_MEM_HOST) {
+    for (int64_t i = 0; i < rows; ++i) deg[i] = h[i];
+  } else {
+    std::vector<int64_t> h64(h.begin(), h.end());
+    SS_HIP(hipMemcpy(deg, h64.data(), rows * sizeof(int64_t), hipMemcpyHostToDevice));
+  }
+  return SS_OK;
+}
+
+template <class T>
+static int spread_impl(const T* G, int64_t rows, int64_t cols, int64_t ld, T* W, int64_t ldw, int mem) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (rows < 0 || cols < 0 || ld < rows || ldw < rows) return fail(SS_EINVAL, "spread: bad shape / leading dimension");
+  if (rows * cols == 0) return SS_OK;
+  if (!G || !W) return fail(SS_EINVAL, "spread: NULL buffer");
+  hipStream_t st = ctx().stream;
+  DevBuf<T> din, dout;
+  DevBuf<int> deg;
+  SS_TRY(deg.alloc(rows));
+  const T* src = G;
+  T* dst = W;
+  int64_t sld = ld, dld = ldw;
+  if (mem == SS_MEM_HOST) {
+    SS_TRY(din.alloc((size_t)rows * cols));
+    SS_TRY(dout.alloc((size_t)rows * cols));
+    SS_HIP(hipMemcpy2DAsync(din.p, rows * sizeof(T), G, ld * sizeof(T), rows * sizeof(T), cols, hipMemcpyHostToDevice, st));
+    src = din.p; dst = dout.p; sld = rows; dld = rows;
+  }
+  SS_TRY(launch_row_degree<T>(src, rows, cols, sld, deg.p));
+  SS_TRY(launch_spread_dense<T>(src, rows, cols, sld, deg.p, dst, dld));
+  if (mem == SS_MEM_HOST)
+    SS_HIP(hipMemcpy2DAsync(W, ldw * sizeof(T), dout.p, rows * sizeof(T), rows * sizeof(T), cols, hipMemcpyDeviceToHost, st));
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ graph handles
+template <class T>
+struct GraphBox {
+  int dtype;  // 4 or 8 = sizeof(T), guards against mixing _f32/_f64 entry points
+  Graph<T> g;
+};
+template <class T>
+struct SpMatBox {
+  int dtype;
+  SpMat<T> m;
+};
+
+template <class T>
+static int graph_check(const void* h, Graph<T>** out) {
+  if (!h) return fail(SS_EINVAL, "graph handle is NULL");
+  GraphBox<T>* b = const_cast<GraphBox<T>*>(reinterpret_cast<const GraphBox<T>*>(h));
+  if (b->dtype != (int)sizeof(T)) return fail(SS_EINVAL, "graph handle was created with the other precision");
+  *out = &b->g;
+  return SS_OK;
+}
+
+template <class T>
+static int graph_create_csr_impl(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const int64_t* xq_ptr,
+                                 const int32_t* xq_idx, const T* xq_val, const int64_t* xs_ptr, const int32_t* xs_idx,
+                                 const T* xs_val, const int64_t* ys_ptr, const int32_t* ys_idx, const T* ys_val,
+                                 int index_base, int mem, ss_graph** out) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (!out) return fail(SS_EINVAL, "out handle pointer is NULL");
+  *out = nullptr;
+  if (nq < 0 || ns < 0 || nf < 0 || nt < 0) return fail(SS_EINVAL, "negative node count");
+  GraphBox<T>* box = new (std::nothrow) GraphBox<T>();
+  if (!box) return fail(SS_ENOMEM, "host allocation failed");
+  box->dtype = (int)sizeof(T);
+  Graph<T>& g = box->g;
+  g.nq = nq; g.ns = ns; g.nf = nf; g.nt = nt;
+  int rc = csr_from_user<T>(nq, nf, xq_ptr, xq_idx, xq_val, index_base, mem, g.Xq);
+  if (rc == SS_OK) rc = csr_from_user<T>(ns, nf, xs_ptr, xs_idx, xs_val, index_base, mem, g.Xs);
+  if (rc == SS_OK) rc = csr_from_user<T>(ns, nt, ys_ptr, ys_idx, ys_val, index_base, mem, g.Ys);
+  if (rc == SS_OK) rc = graph_finalize<T>(g);
+  if (rc != SS_OK) { delete box; return rc; }
+  *out = reinterpret_cast<ss_graph*>(box);
+  return SS_OK;
+}
+
+template <class T>
+static int graph_create_dense_impl(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const T* Sq, int64_t ldq,
+                                   const T* Ss, int64_t lds, const T* Y, int64_t ldy, int apply_cutoff, T alpha,
+                                   int weighted, int mem, ss_graph** out) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (!out) return fail(SS_EINVAL, "out handle pointer is NULL");
+  *out = nullptr;
+  if (nq < 0 || ns < 0 || nf < 0 || nt < 0) return fail(SS_EINVAL, "negative node count");
+  GraphBox<T>* box = new (std::nothrow) GraphBox<T>();
+  if (!box) return fail(SS_ENOMEM, "host allocation failed");
+  box->dtype = (int)sizeof(T);
+  Graph<T>& g = box->g;
+  g.nq = nq; g.ns = ns; g.nf = nf; g.nt = nt;
+  int rc = csr_from_dense<T>(Sq, nq, nf, ldq, apply_cutoff != 0, alpha, weighted != 0, mem, g.Xq);
+  if (rc == SS_OK) rc = csr_from_dense<T>(Ss, ns, nf, lds, apply_cutoff != 0, alpha, weighted != 0, mem, g.Xs);
+  if (rc == SS_OK) rc = csr_from_dense<T>(Y, ns, nt, ldy, false, T(0), true, mem, g.Ys);
+  if (rc == SS_OK) rc = graph_finalize<T>(g);
+  if (rc != SS_OK) { delete box; return rc; }
+  *out = reinterpret_cast<ss_graph*>(box);
+  return SS_OK;
+}
+
+template <class T>
+static int graph_create_general_impl(int64_t n, int64_t nr, int64_t nc, const int64_t* l_ptr, const int32_t* l_idx,
+                                     const T* l_val, const int64_t* b_ptr, const int32_t* b_idx, const T* b_val,
+                                     const int64_t* w_ptr, const int32_t* w_idx, const T* w_val, int index_base,
+                                     int mem, ss_graph** out) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (!out) return fail(SS_EINVAL, "out handle pointer is NULL");
+  *out = nullptr;
+  if (n < 0 || nr < 0 || nc < 0) return fail(SS_EINVAL, "negative node count");
+  GraphBox<T>* box = new (std::nothrow) GraphBox<T>();
+  if (!box) return fail(SS_ENOMEM, "host allocation failed");
+  box->dtype = (int)sizeof(T);
+  Graph<T>& g = box->g;
+  g.general = true;
+  g.nq = nr; g.ns = n; g.nf = n; g.nt = nc;
+  int rc = csr_from_user<T>(nr, n, l_ptr, l_idx, l_val, index_base, mem, g.Xq);
+  if (rc == SS_OK) rc = csr_from_user<T>(n, n, b_ptr, b_idx, b_val, index_base, mem, g.XsT);
+  if (rc == SS_OK) rc = csr_from_user<T>(nc, n, w_ptr, w_idx, w_val, index_base, mem, g.YsT);
+  if (rc == SS_OK) rc = graph_finalize_general<T>(g);
+  if (rc != SS_OK) { delete box; return rc; }
+  *out = reinterpret_cast<ss_graph*>(box);
+  return SS_OK;
+}
+
+// stage-2 operand of a graph: W = Ys' cut for the tile width of this precision
+template <class T>
+static int graph_sell(Graph<T>& g) {
+  const int qt = sell_tile_width<T>();
+  if (g.W_qt == qt) return SS_OK;
+  int kcmax = sell_max_chunk<T>(qt);
+  if (const char* e = getenv("SS_SELL_CHUNK")) {
+    const int v = atoi(e);
+    if (v >= 64 && v < kcmax) kcmax = v;
+  }
+  SS_TRY(sell_build<T>(g.YsT, kcmax, g.W));
+  g.W_qt = qt;
+  return SS_OK;
+}
+
+// rows of T held at once (stage-1 output, stage-2 input)
+static int64_t transfer_batch_rows(int64_t nrows, int64_t nj, size_t elem) {
+  int64_t cap_bytes = 2LL << 30;
+  if (const char* e = getenv("SS_TRANSFER_BYTES")) {
+    const long long v = atoll(e);
+    if (v >= (1 << 20)) cap_bytes = v;
+  }
+  int64_t rb = cap_bytes / ((nj > 0 ? nj : 1) * (int64_t)elem);
+  rb &= ~7LL;
+  if (rb < 8) rb = 8;
+  return rb < nrows ? rb : nrows;
+}
+
+// run stage 1 + stage 2 over [row_begin, row_end) into dev_out (row-major nrows x nt, ld = ldo)
+template <class T>
+static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t row_end, int clean, T* dev_out,
+                               int64_t ldo) {
+  const int64_t nrows = row_end - row_begin;
+  const int64_t nj = g.ns;
+  SS_TRY(graph_sell(g));
+  const int64_t rb = transfer_batch_rows(nrows, nj, sizeof(T));
+  // the transfer block lives in the handle so that repeated predictions do not re-allocate
+  const size_t need = (size_t)rb * (size_t)(nj > 0 ? nj : 1);
+  if (g.Tws.n < need) SS_TRY(g.Tws.alloc(need));
+  DevBuf<T>& Tbuf = g.Tws;
+  for (int64_t r0 = 0; r0 < nrows; r0 += rb) {
+    const int64_t nb = (nrows - r0 < rb) ? (nrows - r0) : rb;
+    {
+      StageTimer t1(ST_TRANSFER);
+      if (kind == 2) {
+        SS_TRY(launch_transfer_loo<T>(g.Xs, g.XsT, g.kf.p, g.ks.p, row_begin + r0, nb, Tbuf.p, nj));
+      } else if (kind == SS_ROWS_QUERY) {
+        const DevCsr<T>* L[2] = {&g.Xq, nullptr};
+        const DevCsr<T>* M[2] = {&g.XsT, nullptr};
+        const T* inv1[2] = {g.inv_kf.p, nullptr};
+        SS_TRY(launch_transfer<T>(1, L, inv1, M, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj));
+      } else {
+        // source rows: feature path + target path
+        const DevCsr<T>* L[2] = {&g.Xs, &g.Ys};
+        const DevCsr<T>* M[2] = {&g.XsT, &g.YsT};
+        const T* inv1[2] = {g.inv_kf.p, g.inv_kt.p};
+        SS_TRY(launch_transfer<T>(2, L, inv1, M, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj));
+      }
+      timing_count(ST_NTRANSFER, 1);
+    }
+    {
+      StageTimer t2(ST_SPMM);
+      SS_TRY(launch_spmm_sell<T>(g.W, Tbuf.p, nj, nb, dev_out + r0 * ldo, ldo, clean ? g.kt.p : nullptr));
+      timing_count(ST_NSPMM, 1);
+    }
+  }
+  if (kind == 2 && clean) {
+    StageTimer t3(ST_EPILOGUE);
+    SS_TRY(launch_loo_clean_fix<T>(g.YsT, g.kt.p, row_begin, nrows, dev_out, ldo));
+  }
+  return SS_OK;
+}
+
+// kind: SS_ROWS_QUERY, SS_ROWS_SOURCE, or 2 = leave-one-out
+template <class T>
+static int predict_impl(ss_graph* h, int kind, int64_t row_begin, int64_t row_end, int clean, T* out, int64_t ld,
+                        int layout, int mem) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  SS_TRY(check_layout(layout));
+  Graph<T>* gp = nullptr;
+  SS_TRY(graph_check<T>(h, &gp));
+  Graph<T>& g = *gp;
+  const int64_t limit = (kind == SS_ROWS_QUERY) ? g.nq : g.ns;
+  if (g.general && kind != SS_ROWS_QUERY)
+    return fail(SS_EINVAL, "a general graph serves SS_ROWS_QUERY only");
+  if (kind == 2) {
+    if (g.nq != 0 || g.ns != g.nf)
+      return fail(SS_EINVAL, "leave-one-out needs a graph with nq == 0 and ns == nf (feature j named after source j)");
+  } else if (kind != SS_ROWS_QUERY && kind != SS_ROWS_SOURCE) {
+    return fail(SS_EINVAL, "rows_kind must be SS_ROWS_QUERY or SS_ROWS_SOURCE");
+  }
+  if (row_begin < 0 || row_end < row_begin || row_end > limit)
+    return fail(SS_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end,
+                (long long)limit);
+  const int64_t nrows = row_end - row_begin;
+  const int64_t nt = g.nt;
+  if (nrows == 0 || nt == 0) return SS_OK;
+  if (!out) return fail(SS_EINVAL, "output buffer is NULL");
+  const int64_t need_ld = (layout == SS_LAYOUT_ROWMAJOR) ? nt : nrows;
+  if (ld < need_ld) return fail(SS_EINVAL, "leading dimension %lld < %lld", (long long)ld, (long long)need_ld);
+  hipStream_t st = ctx().stream;
+  timing_begin_call();
+  hipEvent_t e_begin, e_end;
+  SS_TRY(timing_mark(&e_begin));
+
+  const bool direct = (mem == SS_MEM_DEVICE && layout == SS_LAYOUT_ROWMAJOR);
+  DevBuf<T> scores;  // row-major nrows x nt
+  T* dev_rm = out;
+  int64_t ld_rm = ld;
+  if (!direct) {
+    SS_TRY(scores.alloc((size_t)nrows * nt));
+    dev_rm = scores.p;
+    ld_rm = nt;
+  }
+  SS_TRY(predict_rows_device<T>(g, kind, row_begin, row_end, clean, dev_rm, ld_rm));
+
+  DevBuf<T> cm;  // column-major staging when the caller is on the host
+  if (layout == SS_LAYOUT_COLMAJOR) {
+    StageTimer t3(ST_EPILOGUE);
+    T* dst = out;
+    int64_t dld = ld;
+    if (mem == SS_MEM_HOST) {
+      SS_TRY(cm.alloc((size_t)nrows * nt));
+      dst = cm.p;
+      dld = nrows;
+    }
+    SS_TRY(launch_transpose<T>(dev_rm, nrows, nt, ld_rm, dst, dld));
+  }
+  SS_TRY(timing_mark(&e_end));
+  timing_span(ST_TOTAL, e_begin, e_end);
+  if (mem == SS_MEM_HOST) {
+    StageTimer t5(ST_D2H);
+    if (layout == SS_LAYOUT_ROWMAJOR) {
+      SS_HIP(hipMemcpy2DAsync(out, ld * sizeof(T), dev_rm, ld_rm * sizeof(T), nt * sizeof(T), nrows,
+                              hipMemcpyDeviceToHost, st));
+    } else {
+      SS_HIP(hipMemcpy2DAsync(out, ld * sizeof(T), cm.p, nrows * sizeof(T), nrows * sizeof(T), nt,
+                              hipMemcpyDeviceToHost, st));
+    }
+    t5.stop();
+  }
+  // temporaries (transfer block, staging) are released on return: wait for the stream
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ raw SpMM
+template <class T>
+static int spmat_check(const void* h, SpMat<T>** out) {
+  if (!h) return fail(SS_EINVAL, "matrix handle is NULL");
+  SpMatBox<T>* b = const_cast<SpMatBox<T>*>(reinterpret_cast<const SpMatBox<T>*>(h));
+  if (b->dtype != (int)sizeof(T)) return fail(SS_EINVAL, "matrix handle was created with the other precision");
+  *out = &b->m;
+  return SS_OK;
+}
+
+template <class T>
+static int spmat_create_impl(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const T* val,
+                             int index_base, int mem, ss_spmat** out) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (!out) return fail(SS_EINVAL, "out handle pointer is NULL");
+  *out = nullptr;
+  SpMatBox<T>* box = new (std::nothrow) SpMatBox<T>();
+  if (!box) return fail(SS_ENOMEM, "host allocation failed");
+  box->dtype = (int)sizeof(T);
+  int rc = csr_from_user<T>(rows, cols, ptr, idx, val, index_base, mem, box->m.csr);
+  if (rc != SS_OK) { delete box; return rc; }
+  *out = reinterpret_cast<ss_spmat*>(box);
+  return SS_OK;
+}
+
+template <class T>
+static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layout, T* F, int64_t ldf, int f_layout,
+                     int mem) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  SS_TRY(check_layout(r_layout));
+  SS_TRY(check_layout(f_layout));
+  SpMat<T>* mp = nullptr;
+  SS_TRY(spmat_check<T>(h, &mp));
+  SpMat<T>& m = *mp;
+  const int64_t M = m.csr.rows, K = m.csr.cols;
+  if (B < 0) return fail(SS_EINVAL, "B < 0");
+  if (B == 0 || M == 0) return SS_OK;
+  if (!F || (K > 0 && !R)) return fail(SS_EINVAL, "NULL operand");
+  if (ldr < (r_layout == SS_LAYOUT_ROWMAJOR ? B : K)) return fail(SS_EINVAL, "ldr too small");
+  if (ldf < (f_layout == SS_LAYOUT_ROWMAJOR ? B : M)) return fail(SS_EINVAL, "ldf too small");
+  hipStream_t st = ctx().stream;
+  timing_begin_call();
+
+  // stage caller operands on the device in their own layout
+  DevBuf<T> dR, dF;
+  const T* Rd = R;
+  T* Fd = F;
+  int64_t ldr_d = ldr, ldf_d = ldf;
+  if (mem == SS_MEM_HOST) {
+    StageTimer t4(ST_H2D);
+    const int64_t r_outer = (r_layout == SS_LAYOUT_ROWMAJOR) ? K : B, r_inner = (r_layout == SS_LAYOUT_ROWMAJOR) ? B : K;
+    SS_TRY(dR.alloc((size_t)(r_outer > 0 ? r_outer : 1) * r_inner));
+    if (r_outer > 0)
+      SS_HIP(hipMemcpy2DAsync(dR.p, r_inner * sizeof(T), R, ldr * sizeof(T), r_inner * sizeof(T), r_outer,
+                              hipMemcpyHostToDevice, st));
+    Rd = dR.p;
+    ldr_d = r_inner;
+    const int64_t f_outer = (f_layout == SS_LAYOUT_ROWMAJOR) ? M : B, f_inner = (f_layout == SS_LAYOUT_ROWMAJOR) ? B : M;
+    SS_TRY(dF.alloc((size_t)f_outer * f_inner));
+    Fd = dF.p;
+    ldf_d = f_inner;
+  }
+  hipEvent_t e_begin, e_end;
+  SS_TRY(timing_mark(&e_begin));
+  const bool narrow = (B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR);
+  DevBuf<T> Rt, Ft;
+  if (narrow) {
+    StageTimer t2(ST_SPMM);
+    SS_TRY(launch_spmm_csr_narrow<T>(m.csr, Rd, ldr_d, (int)B, Fd, ldf_d));
+    timing_count(ST_NSPMM, 1);
+  } else {
+    const int qt = sell_tile_width<T>();
+    if (m.sell_qt != qt) {
+      int kcmax = sell_max_chunk<T>(qt);
+      if (const char* e = getenv("SS_SELL_CHUNK")) {
+        const int v = atoi(e);
+        if (v >= 64 && v < kcmax) kcmax = v;
+      }
+      SS_TRY(sell_build<T>(m.csr, kcmax, m.sell));
+      m.sell_qt = qt;
+    }
+    const T* Rc = Rd;   // column-major view: R(k,b) at Rc[b*ldrc + k]
+    int64_t ldrc = ldr_d;
+    if (r_layout == SS_LAYOUT_ROWMAJOR) {
+      StageTimer t3(ST_EPILOGUE);
+      SS_TRY(Rt.alloc((size_t)B * (K > 0 ? K : 1)));
+      SS_TRY(launch_transpose<T>(Rd, K, B, ldr_d, Rt.p, K));
+      Rc = Rt.p;
+      ldrc = K;
+    }
+    T* Fc = Fd;
+    int64_t ldfc = ldf_d;
+    if (f_layout == SS_LAYOUT_ROWMAJOR) {
+      SS_TRY(Ft.alloc((size_t)B * M));
+      Fc = Ft.p;
+      ldfc = M;
+    }
+    {
+      StageTimer t2(ST_SPMM);
+      SS_TRY(launch_spmm_sell<T>(m.sell, Rc, ldrc, B, Fc, ldfc, nullptr));
+      timing_count(ST_NSPMM, 1);
+    }
+    if (f_layout == SS_LAYOUT_ROWMAJOR) {
+      StageTimer t3(ST_EPILOGUE);
+      SS_TRY(launch_transpose<T>(Fc, B, M, ldfc, Fd, ldf_d));
+    }
+  }
+  SS_TRY(timing_mark(&e_end));
+  timing_span(ST_TOTAL, e_begin, e_end);
+  if (mem == SS_MEM_HOST) {
+    StageTimer t5(ST_D2H);
+    const int64_t f_outer = (f_layout == SS_LAYOUT_ROWMAJOR) ? M : B, f_inner = (f_layout == SS_LAYOUT_ROWMAJOR) ? B : M;
+    SS_HIP(hipMemcpy2DAsync(F, ldf * sizeof(T), dF.p, f_inner * sizeof(T), f_inner * sizeof(T), f_outer,
+                            hipMemcpyDeviceToHost, st));
+    t5.stop();
+  }
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
+}  // namespace ss
+
+// ==================================================================== extern "C"
+using namespace ss;
+
+extern "C" {
+
+int ss_version(void) { return SS_VERSION; }
+
+const char* ss_last_error(void) { return last_error().c_str(); }
+
+int ss_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ss_init(int device) {
+  Ctx& c = ctx();
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(SS_ENODEV, "no HIP device visible (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(SS_EINVAL, "device %d outside 0..%d", device, n - 1);
+  if (c.inited && c.device == device) return SS_OK;
+  if (c.inited) ss_shutdown();
+  SS_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SS_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SS_ENODEV, "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+  c.num_cu = prop.multiProcessorCount;
+  SS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.device = device;
+  c.inited = true;
+  return SS_OK;
+}
+
+int ss_shutdown(void) {
+  Ctx& c = ctx();
+  if (!c.inited) return SS_OK;
+  (void)hipStreamSynchronize(c.stream);
+  for (hipEvent_t e : c.timing.pool) (void)hipEventDestroy(e);
+  c.timing.pool.clear();
+  c.timing.spans.clear();
+  c.timing.used = 0;
+  (void)hipStreamDestroy(c.stream);
+  c.stream = nullptr;
+  c.inited = false;
+  c.device = -1;
+  return SS_OK;
+}
+
+int ss_synchronize(void) {
+  SS_TRY(require_init());
+  SS_HIP(hipStreamSynchronize(ctx().stream));
+  return SS_OK;
+}
+
+int ss_timing_last(double* ms, int n) {
+  SS_TRY(require_init());
+  if (!ms || n <= 0) return fail(SS_EINVAL, "ss_timing_last: bad buffer");
+  Timing& t = ctx().timing;
+  if (t.dirty) {
+    SS_HIP(hipStreamSynchronize(ctx().stream));
+    for (double& r : t.resolved) r = 0;
+    for (const Timing::Span& s : t.spans) {
+      float f = 0;
+      SS_HIP(hipEventElapsedTime(&f, s.a, s.b));
+      t.resolved[s.stage] += f;
+    }
+    t.resolved[ST_NSPMM] = t.extra[ST_NSPMM];
+    t.resolved[ST_NTRANSFER] = t.extra[ST_NTRANSFER];
+    t.dirty = false;
+  }
+  for (int i = 0; i < n && i < 8; ++i) ms[i] = t.resolved[i];
+  return SS_OK;
+}
+
+int ss_cutoff_f32(const float* X, int64_t rows, int64_t cols, int64_t ld, float alpha, int weighted, float* out,
+                  int64_t ldo, int mem) {
+  return cutoff_impl<float>(X, rows, cols, ld, alpha, weighted, out, ldo, mem);
+}
+int ss_cutoff_f64(const double* X, int64_t rows, int64_t cols, int64_t ld, double alpha, int weighted, double* out,
+                  int64_t ldo, int mem) {
+  return cutoff_impl<double>(X, rows, cols, ld, alpha, weighted, out, ldo, mem);
+}
+int ss_row_degree_f32(const float* G, int64_t rows, int64_t cols, int64_t ld, int64_t* deg, int mem) {
+  return row_degree_impl<float>(G, rows, cols, ld, deg, mem);
+}
+int ss_row_degree_f64(const double* G, int64_t rows, int64_t cols, int64_t ld, int64_t* deg, int mem) {
+  return row_degree_impl<double>(G, rows, cols, ld, deg, mem);
+}
+int ss_spread_f32(const float* G, int64_t rows, int64_t cols, int64_t ld, float* W, int64_t ldw, int mem) {
+  return spread_impl<float>(G, rows, cols, ld, W, ldw, mem);
+}
+int ss_spread_f64(const double* G, int64_t rows, int64_t cols, int64_t ld, double* W, int64_t ldw, int mem) {
+  return spread_impl<double>(G, rows, cols, ld, W, ldw, mem);
+}
+
+int ss_graph_create_csr_f32(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const int64_t* xq_ptr,
+                            const int32_t* xq_idx, const float* xq_val, const int64_t* xs_ptr, const int32_t* xs_idx,
+                            const float* xs_val, const int64_t* ys_ptr, const int32_t* ys_idx, const float* ys_val,
+                            int index_base, int mem, ss_graph** out) {
+  return graph_create_csr_impl<float>(nq, ns, nf, nt, xq_ptr, xq_idx, xq_val, xs_ptr, xs_idx, xs_val, ys_ptr, ys_idx,
+                                      ys_val, index_base, mem, out);
+}
+int ss_graph_create_csr_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const int64_t* xq_ptr,
+                            const int32_t* xq_idx, const double* xq_val, const int64_t* xs_ptr, const int32_t* xs_idx,
+                            const double* xs_val, const int64_t* ys_ptr, const int32_t* ys_idx, const double* ys_val,
+                            int index_base, int mem, ss_graph** out) {
+  return graph_create_csr_impl<double>(nq, ns, nf, nt, xq_ptr, xq_idx, xq_val, xs_ptr, xs_idx, xs_val, ys_ptr, ys_idx,
+                                       ys_val, index_base, mem, out);
+}
+int ss_graph_create_dense_f32(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const float* Sq, int64_t ldq,
+                              const float* Ss, int64_t lds, const float* Y, int64_t ldy, int apply_cutoff, float alpha,
+                              int weighted, int mem, ss_graph** out) {
+  return graph_create_dense_impl<float>(nq, ns, nf, nt, Sq, ldq, Ss, lds, Y, ldy, apply_cutoff, alpha, weighted, mem,
+                                        out);
+}
+int ss_graph_create_dense_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const double* Sq, int64_t ldq,
+                              const double* Ss, int64_t lds, const double* Y, int64_t ldy, int apply_cutoff,
+                              double alpha, int weighted, int mem, ss_graph** out) {
+  return graph_create_dense_impl<double>(nq, ns, nf, nt, Sq, ldq, Ss, lds, Y, ldy, apply_cutoff, alpha, weighted, mem,
+                                         out);
+}
+
+int ss_graph_create_general_f32(int64_t n, int64_t nr, int64_t nc, const int64_t* l_ptr, const int32_t* l_idx,
+                                const float* l_val, const int64_t* b_ptr, const int32_t* b_idx, const float* b_val,
+                                const int64_t* w_ptr, const int32_t* w_idx, const float* w_val, int index_base, int mem,
+                                ss_graph** out) {
+  return graph_create_general_impl<float>(n, nr, nc, l_ptr, l_idx, l_val, b_ptr, b_idx, b_val, w_ptr, w_idx, w_val,
+                                          index_base, mem, out);
+}
+int ss_graph_create_general_f64(int64_t n, int64_t nr, int64_t nc, const int64_t* l_ptr, const int32_t* l_idx,
+                                const double* l_val, const int64_t* b_ptr, const int32_t* b_idx, const double* b_val,
+                                const int64_t* w_ptr, const int32_t* w_idx, const double* w_val, int index_base,
+                                int mem, ss_graph** out) {
+  return graph_create_general_impl<double>(n, nr, nc, l_ptr, l_idx, l_val, b_ptr, b_idx, b_val, w_ptr, w_idx, w_val,
+                                           index_base, mem, out);
+}
+
+int ss_graph_destroy(ss_graph* h) {
+  if (!h) return SS_OK;
+  if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
+  const int dtype = *reinterpret_cast<int*>(h);
+  if (dtype == 4) delete reinterpret_cast<GraphBox<float>*>(h);
+  else if (dtype == 8) delete reinterpret_cast<GraphBox<double>*>(h);
+  else return fail(SS_EINVAL, "not a graph handle");
+  return SS_OK;
+}
+
+int ss_graph_info(const ss_graph* h, int64_t sizes[7]) {
+  if (!h || !sizes) return fail(SS_EINVAL, "NULL argument");
+  const int dtype = *reinterpret_cast<const int*>(h);
+  auto fill = [&](auto* b) {
+    sizes[0] = b->g.nq; sizes[1] = b->g.ns; sizes[2] = b->g.nf; sizes[3] = b->g.nt;
+    sizes[4] = b->g.Xq.nnz; sizes[5] = b->g.Xs.nnz; sizes[6] = b->g.Ys.nnz;
+  };
+  if (dtype == 4) fill(reinterpret_cast<const GraphBox<float>*>(h));
+  else if (dtype == 8) fill(reinterpret_cast<const GraphBox<double>*>(h));
+  else return fail(SS_EINVAL, "not a graph handle");
+  return SS_OK;
+}
+
+int ss_graph_degrees(const ss_graph* h, int64_t* kf, int64_t* ks, int64_t* kt) {
+  SS_TRY(require_init());
+  if (!h) return fail(SS_EINVAL, "graph handle is NULL");
+  const int dtype = *reinterpret_cast<const int*>(h);
+  auto pull = [&](const DevBuf<int>& d, int64_t n, int64_t* out) -> int {
+    if (!out || n == 0) return SS_OK;
+    std::vector<int> tmp(n);
+    SS_HIP(hipMemcpyAsync(tmp.data(), d.p, n * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+    SS_HIP(hipStreamSynchronize(ctx().stream));
+    for (int64_t i = 0; i < n; ++i) out[i] = tmp[i];
+    return SS_OK;
+  };
+  auto run = [&](auto* b) -> int {
+    SS_TRY(pull(b->g.kf, b->g.nf, kf));
+    SS_TRY(pull(b->g.ks, b->g.ns, ks));
+    SS_TRY(pull(b->g.kt, b->g.nt, kt));
+    return SS_OK;
+  };
+  if (dtype == 4) return run(reinterpret_cast<const GraphBox<float>*>(h));
+  if (dtype == 8) return run(reinterpret_cast<const GraphBox<double>*>(h));
+  return fail(SS_EINVAL, "not a graph handle");
+}
+
+int ss_predict_f32(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean, float* out, int64_t ld,
+                   int layout, int mem) {
+  if (rows_kind != SS_ROWS_QUERY && rows_kind != SS_ROWS_SOURCE) return fail(SS_EINVAL, "bad rows_kind");
+  return predict_impl<float>(g, rows_kind, row_begin, row_end, clean, out, ld, layout, mem);
+}
+int ss_predict_f64(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean, double* out, int64_t ld,
+                   int layout, int mem) {
+  if (rows_kind != SS_ROWS_QUERY && rows_kind != SS_ROWS_SOURCE) return fail(SS_EINVAL, "bad rows_kind");
+  return predict_impl<double>(g, rows_kind, row_begin, row_end, clean, out, ld, layout, mem);
+}
+int ss_predict_loo_f32(ss_graph* g, int64_t i_begin, int64_t i_end, int clean, float* out, int64_t ld, int layout,
+                       int mem) {
+  return predict_impl<float>(g, 2, i_begin, i_end, clean, out, ld, layout, mem);
+}
+int ss_predict_loo_f64(ss_graph* g, int64_t i_begin, int64_t i_end, int clean, double* out, int64_t ld, int layout,
+                       int mem) {
+  return predict_impl<double>(g, 2, i_begin, i_end, clean, out, ld, layout, mem);
+}
+
+int ss_spmat_create_csr_f32(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const float* val,
+                            int index_base, int mem, ss_spmat** out) {
+  return spmat_create_impl<float>(rows, cols, ptr, idx, val, index_base, mem, out);
+}
+int ss_spmat_create_csr_f64(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const double* val,
+                            int index_base, int mem, ss_spmat** out) {
+  return spmat_create_impl<double>(rows, cols, ptr, idx, val, index_base, mem, out);
+}
+int ss_spmat_destroy(ss_spmat* h) {
+  if (!h) return SS_OK;
+  if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
+  const int dtype = *reinterpret_cast<int*>(h);
+  if (dtype == 4) delete reinterpret_cast<SpMatBox<float>*>(h);
+  else if (dtype == 8) delete reinterpret_cast<SpMatBox<double>*>(h);
+  else return fail(SS_EINVAL, "not a matrix handle");
+  return SS_OK;
+}
+int ss_spmm_f32(ss_spmat* w, const float* R, int64_t B, int64_t ldr, int r_layout, float* F, int64_t ldf, int f_layout,
+                int mem) {
+  return spmm_impl<float>(w, R, B, ldr, r_layout, F, ldf, f_layout, mem);
+}
+int ss_spmm_f64(ss_spmat* w, const double* R, int64_t B, int64_t ldr, int r_layout, double* F, int64_t ldf,
+                int f_layout, int mem) {
+  return spmm_impl<double>(w, R, B, ldr, r_layout, F, ldf, f_layout, mem);
+}
+int ss_spmat_cost(const ss_spmat* h, int64_t B, double* bytes, double* flops) {
+  if (!h) return fail(SS_EINVAL, "matrix handle is NULL");
+  const int dtype = *reinterpret_cast<const int*>(h);
+  int64_t rows, cols, nnz;
+  if (dtype == 4) { auto* b = reinterpret_cast<const SpMatBox<float>*>(h); rows = b->m.csr.rows; cols = b->m.csr.cols; nnz = b->m.csr.nnz; }
+  else if (dtype == 8) { auto* b = reinterpret_cast<const SpMatBox<double>*>(h); rows = b->m.csr.rows; cols = b->m.csr.cols; nnz = b->m.csr.nnz; }
+  else return fail(SS_EINVAL, "not a matrix handle");
+  const double vb = dtype;
+  if (bytes) *bytes = (double)nnz * (vb + 4) + (double)(rows + 1) * 4 + (double)cols * B * vb + (double)rows * B * vb;
+  if (flops) *flops = 2.0 * (double)nnz * (double)B;
+  return SS_OK;
+}
+
+}  // extern "C"

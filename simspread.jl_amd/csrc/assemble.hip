@@ -1,0 +1,577 @@
+// Device-side assembly of the tri-partite graph: the blocks Xq, Xs, Ys of construct's block
+// adjacency (src/core.jl:165-187) become CSR operands on the GPU, with the featurize cutoff
+// (src/core.jl:106-112) fused into the dense -> CSR compaction; the N x N matrices A and B of
+// the reference are never formed.  Degrees are non-zero COUNTS (src/graphs.jl:9-11).
+//
+// Set-up path only (runs once per graph): rocPRIM supplies the scan and the stable radix sort
+// used for the transposes; the per-prediction kernels live in kernels.hip.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "graph.hpp"
+
+namespace ss {
+
+#define SS_LAUNCH_CHECK()                                                             \
+  do {                                                                                \
+    hipError_t _e = hipGetLastError();                                                \
+    if (_e != hipSuccess)                                                             \
+      return fail(SS_EHIP, "%s:%d kernel launch: %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+  } while (0)
+
+static inline int grid_for(int64_t work, int block, int cap = 256 * 16) {
+  int64_t g = ceil_div(work, block);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+__global__ void scan_tail_kernel(const int* in, int* out, int64_t n) { out[n] = out[n - 1] + in[n - 1]; }
+
+// exclusive scan of n ints, out[n] = total (out has n+1 entries)
+static int exclusive_scan_int(const int* in, int* out, int64_t n) {
+  hipStream_t st = ctx().stream;
+  if (n == 0) {
+    SS_HIP(hipMemsetAsync(out, 0, sizeof(int), st));
+    return SS_OK;
+  }
+  size_t bytes = 0;
+  SS_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), st));
+  DevBuf<unsigned char> tmp;
+  SS_TRY(tmp.alloc(bytes));
+  SS_HIP(rocprim::exclusive_scan(tmp.p, bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), st));
+  // total = out[n-1] + in[n-1]
+  hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(1), 0, st, in, out, n);
+  SS_LAUNCH_CHECK();
+  SS_HIP(hipStreamSynchronize(st));  // tmp is freed on return
+  return SS_OK;
+}
+
+static int read_int(const int* dev, int* host) {
+  SS_HIP(hipMemcpyAsync(host, dev, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+  SS_HIP(hipStreamSynchronize(ctx().stream));
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ user CSR -> canonical CSR
+// wave per row: validate (monotone pointers, indices in range and strictly increasing) and count
+// the non-zero values; status bits: 1 bad pointer, 2 index out of range, 4 unsorted/duplicate
+template <class T>
+__global__ void csr_check_count_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                       const T* __restrict__ val, int64_t rows, int64_t cols, int base,
+                                       int64_t nnz_in, int* __restrict__ cnt, int* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave0; r < rows; r += nwaves) {
+    const int64_t b = ptr[r] - base, e = ptr[r + 1] - base;
+    if (b < 0 || e < b || e > nnz_in) {
+      if (lane == 0) atomicOr(status, 1);
+      if (lane == 0) cnt[r] = 0;
+      continue;
+    }
+    int n = 0;
+    for (int64_t x = b + lane; x < e; x += 64) {
+      const int64_t c = (int64_t)idx[x] - base;
+      if (c < 0 || c >= cols) atomicOr(status, 2);
+      if (x > b && (int64_t)idx[x - 1] - base >= c) atomicOr(status, 4);
+      const bool nz = val ? (val[x] != T(0)) : true;
+      n += nz ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if (lane == 0) cnt[r] = n;
+  }
+}
+
+template <class T>
+__global__ void csr_compact_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                   const T* __restrict__ val, int64_t rows, int base, const int* __restrict__ optr,
+                                   int* __restrict__ oidx, T* __restrict__ oval, int* __restrict__ not_binary) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave0; r < rows; r += nwaves) {
+    const int64_t b = ptr[r] - base, e = ptr[r + 1] - base;
+    int o = optr[r];
+    for (int64_t x0 = b; x0 < e; x0 += 64) {
+      const int64_t x = x0 + lane;
+      const bool in = x < e;
+      const T v = in ? (val ? val[x] : T(1)) : T(0);
+      const bool keep = in && v != T(0);
+      const unsigned long long mask = __ballot(keep);
+      const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+      if (keep) {
+        oidx[o + pos] = idx[x] - base;
+        oval[o + pos] = v;
+        if (v != T(1)) *not_binary = 1;
+      }
+      o += __popcll(mask);
+    }
+  }
+}
+
+template <class T>
+int csr_from_user(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const T* val,
+                  int index_base, int mem, DevCsr<T>& out) {
+  hipStream_t st = ctx().stream;
+  if (rows < 0 || cols < 0) return fail(SS_EINVAL, "negative matrix size");
+  if (index_base != 0 && index_base != 1) return fail(SS_EINVAL, "index_base must be 0 or 1");
+  out.rows = rows;
+  out.cols = cols;
+  if (rows >= (1LL << 31) - 64 || cols >= (1LL << 31) - 64) return fail(SS_EUNSUPPORTED, "dimension >= 2^31");
+  if (rows == 0) {
+    out.nnz = 0;
+    out.binary = true;
+    SS_TRY(out.ptr.alloc(1));
+    SS_HIP(hipMemsetAsync(out.ptr.p, 0, sizeof(int), st));
+    SS_TRY(out.idx.alloc(0));
+    SS_TRY(out.val.alloc(0));
+    return SS_OK;
+  }
+  if (!ptr) return fail(SS_EINVAL, "row pointer array is NULL");
+  // the last row pointer gives the stored entry count
+  int64_t last = 0, first = 0;
+  if (mem == SS_MEM_HOST) {
+    last = ptr[rows];
+    first = ptr[0];
+  } else {
+    SS_HIP(hipMemcpyAsync(&last, ptr + rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(hipMemcpyAsync(&first, ptr, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(hipStreamSynchronize(st));
+  }
+  if (first != index_base) return fail(SS_EINVAL, "row pointer does not start at index_base");
+  const int64_t nnz_in = last - index_base;
+  if (nnz_in < 0) return fail(SS_EINVAL, "negative entry count in row pointers");
+  if (nnz_in >= (1LL << 31) - 64) return fail(SS_EUNSUPPORTED, "nnz >= 2^31 needs 64-bit row pointers");
+  if (nnz_in > 0 && !idx) return fail(SS_EINVAL, "column index array is NULL");
+
+  DevBuf<int64_t> dptr;
+  DevBuf<int32_t> didx;
+  DevBuf<T> dval;
+  const int64_t* uptr = ptr;
+  const int32_t* uidx = idx;
+  const T* uval = val;
+  if (mem == SS_MEM_HOST) {
+    SS_TRY(dptr.alloc(rows + 1));
+    SS_TRY(upload(dptr.p, ptr, rows + 1, mem));
+    SS_TRY(didx.alloc(nnz_in));
+    SS_TRY(upload(didx.p, idx, nnz_in, mem));
+    if (val) {
+      SS_TRY(dval.alloc(nnz_in));
+      SS_TRY(upload(dval.p, val, nnz_in, mem));
+      uval = dval.p;
+    }
+    uptr = dptr.p;
+    uidx = didx.p;
+  }
+  DevBuf<int> cnt, flags;
+  SS_TRY(cnt.alloc(rows));
+  SS_TRY(flags.alloc(2));
+  SS_HIP(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), st));
+  hipLaunchKernelGGL(csr_check_count_kernel<T>, dim3(grid_for(rows * 64, 256)), dim3(256), 0, st, uptr, uidx, uval,
+                     rows, cols, index_base, nnz_in, cnt.p, flags.p);
+  SS_LAUNCH_CHECK();
+  int status = 0;
+  SS_TRY(read_int(flags.p, &status));
+  if (status & 1) return fail(SS_EINVAL, "row pointers are not monotone / exceed the entry count");
+  if (status & 2) return fail(SS_EINVAL, "column index out of range");
+  if (status & 4) return fail(SS_EINVAL, "column indices must be strictly increasing within a row");
+  SS_TRY(out.ptr.alloc(rows + 1));
+  SS_TRY(exclusive_scan_int(cnt.p, out.ptr.p, rows));
+  int nnz = 0;
+  SS_TRY(read_int(out.ptr.p + rows, &nnz));
+  out.nnz = nnz;
+  SS_TRY(out.idx.alloc(nnz));
+  SS_TRY(out.val.alloc(nnz));
+  hipLaunchKernelGGL(csr_compact_kernel<T>, dim3(grid_for(rows * 64, 256)), dim3(256), 0, st, uptr, uidx, uval,
+                     rows, index_base, out.ptr.p, out.idx.p, out.val.p, flags.p + 1);
+  SS_LAUNCH_CHECK();
+  int notbin = 0;
+  SS_TRY(read_int(flags.p + 1, &notbin));
+  out.binary = (notbin == 0);
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ dense (column-major) -> CSR with the cutoff fused
+template <class T>
+__device__ __forceinline__ bool keep_entry(T x, bool cut, T alpha, bool weighted, T& v) {
+  if (cut) {
+    // cutoff(x, alpha, weighted): x >= alpha ? (weighted ? x : 1) : 0; a kept weight of 0 is no edge
+    const bool k = x >= alpha;
+    v = weighted ? x : T(1);
+    return k && v != T(0);
+  }
+  v = x;
+  return x != T(0);
+}
+
+// grid: (row blocks, column splits); one thread per (row, split); counts[split*rows + row]
+template <class T>
+__global__ void dense_count_kernel(const T* __restrict__ S, int64_t rows, int64_t cols, int64_t ld, int cut,
+                                   T alpha, int weighted, int64_t cols_per_split, int* __restrict__ counts) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t c0 = (int64_t)blockIdx.y * cols_per_split;
+  const int64_t c1 = (c0 + cols_per_split < cols) ? c0 + cols_per_split : cols;
+  int n = 0;
+  for (int64_t c = c0; c < c1; ++c) {
+    T v;
+    n += keep_entry<T>(S[r + c * ld], cut != 0, alpha, weighted != 0, v) ? 1 : 0;
+  }
+  counts[(int64_t)blockIdx.y * rows + r] = n;
+}
+
+// per row: turn the per-split counts into per-split start offsets within the row, emit the row total
+__global__ void dense_row_offsets_kernel(int* __restrict__ counts, int64_t rows, int nsplit, int* __restrict__ rowcnt) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  int run = 0;
+  for (int s = 0; s < nsplit; ++s) {
+    const int c = counts[(int64_t)s * rows + r];
+    counts[(int64_t)s * rows + r] = run;
+    run += c;
+  }
+  rowcnt[r] = run;
+}
+
+template <class T>
+__global__ void dense_fill_kernel(const T* __restrict__ S, int64_t rows, int64_t cols, int64_t ld, int cut, T alpha,
+                                  int weighted, int64_t cols_per_split, const int* __restrict__ offs,
+                                  const int* __restrict__ ptr, int* __restrict__ oidx, T* __restrict__ oval,
+                                  int* __restrict__ not_binary) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t c0 = (int64_t)blockIdx.y * cols_per_split;
+  const int64_t c1 = (c0 + cols_per_split < cols) ? c0 + cols_per_split : cols;
+  int o = ptr[r] + offs[(int64_t)blockIdx.y * rows + r];
+  bool nb = false;
+  for (int64_t c = c0; c < c1; ++c) {
+    T v;
+    if (keep_entry<T>(S[r + c * ld], cut != 0, alpha, weighted != 0, v)) {
+      oidx[o] = (int)c;
+      oval[o] = v;
+      nb |= (v != T(1));
+      ++o;
+    }
+  }
+  if (nb) *not_binary = 1;
+}
+
+template <class T>
+int csr_from_dense(const T* S, int64_t rows, int64_t cols, int64_t ld, bool apply_cutoff, T alpha,
+                   bool weighted, int mem, DevCsr<T>& out) {
+  hipStream_t st = ctx().stream;
+  if (rows < 0 || cols < 0) return fail(SS_EINVAL, "negative matrix size");
+  if (rows > 0 && cols > 0 && (!S || ld < rows)) return fail(SS_EINVAL, "dense block: NULL pointer or ld < rows");
+  if (rows >= (1LL << 31) - 64 || cols >= (1LL << 31) - 64) return fail(SS_EUNSUPPORTED, "dimension >= 2^31");
+  out.rows = rows;
+  out.cols = cols;
+  SS_TRY(out.ptr.alloc(rows + 1));
+  if (rows == 0 || cols == 0) {
+    out.nnz = 0;
+    out.binary = true;
+    SS_HIP(hipMemsetAsync(out.ptr.p, 0, (rows + 1) * sizeof(int), st));
+    SS_TRY(out.idx.alloc(0));
+    SS_TRY(out.val.alloc(0));
+    return SS_OK;
+  }
+  DevBuf<T> dS;
+  const T* src = S;
+  int64_t sld = ld;
+  if (mem == SS_MEM_HOST) {
+    SS_TRY(dS.alloc((size_t)rows * cols));
+    SS_HIP(hipMemcpy2DAsync(dS.p, rows * sizeof(T), S, ld * sizeof(T), rows * sizeof(T), cols,
+                            hipMemcpyHostToDevice, st));
+    src = dS.p;
+    sld = rows;
+  }
+  // enough (row, split) threads to fill the chip: ~64k threads
+  int nsplit = (int)ceil_div(65536, rows);
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > cols) nsplit = (int)cols;
+  if (nsplit > 1024) nsplit = 1024;
+  const int64_t cps = ceil_div(cols, nsplit);
+  nsplit = (int)ceil_div(cols, cps);
+  DevBuf<int> counts, rowcnt, flag;
+  SS_TRY(counts.alloc((size_t)nsplit * rows));
+  SS_TRY(rowcnt.alloc(rows));
+  SS_TRY(flag.alloc(1));
+  SS_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+  dim3 grid((unsigned)ceil_div(rows, 64), (unsigned)nsplit);
+  hipLaunchKernelGGL(dense_count_kernel<T>, grid, dim3(64), 0, st, src, rows, cols, sld, apply_cutoff ? 1 : 0, alpha,
+                     weighted ? 1 : 0, cps, counts.p);
+  SS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dense_row_offsets_kernel, dim3((unsigned)ceil_div(rows, 64)), dim3(64), 0, st, counts.p, rows,
+                     nsplit, rowcnt.p);
+  SS_LAUNCH_CHECK();
+  SS_TRY(exclusive_scan_int(rowcnt.p, out.ptr.p, rows));
+  int nnz = 0;
+  SS_TRY(read_int(out.ptr.p + rows, &nnz));
+  if (nnz < 0) return fail(SS_EUNSUPPORTED, "nnz >= 2^31 needs 64-bit row pointers");
+  out.nnz = nnz;
+  SS_TRY(out.idx.alloc(nnz));
+  SS_TRY(out.val.alloc(nnz));
+  hipLaunchKernelGGL(dense_fill_kernel<T>, grid, dim3(64), 0, st, src, rows, cols, sld, apply_cutoff ? 1 : 0, alpha,
+                     weighted ? 1 : 0, cps, counts.p, out.ptr.p, out.idx.p, out.val.p, flag.p);
+  SS_LAUNCH_CHECK();
+  int notbin = 0;
+  SS_TRY(read_int(flag.p, &notbin));
+  out.binary = (notbin == 0);
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ transpose (stable sort by column)
+__global__ void expand_rows_kernel(const int* __restrict__ ptr, int64_t rows, int* __restrict__ rowid,
+                                   int* __restrict__ iota) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave0; r < rows; r += nwaves) {
+    const int b = ptr[r], e = ptr[r + 1];
+    for (int x = b + lane; x < e; x += 64) {
+      rowid[x] = (int)r;
+      iota[x] = x;
+    }
+  }
+}
+
+__global__ void histogram_kernel(const int* __restrict__ keys, int64_t n, int* __restrict__ hist) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&hist[keys[i]], 1);
+}
+
+template <class T>
+__global__ void gather_transpose_kernel(const int* __restrict__ perm, const int* __restrict__ rowid,
+                                        const T* __restrict__ val, int64_t n, int* __restrict__ oidx,
+                                        T* __restrict__ oval) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = perm[i];
+    oidx[i] = rowid[p];
+    oval[i] = val[p];
+  }
+}
+
+template <class T>
+int csr_transpose(const DevCsr<T>& in, DevCsr<T>& out) {
+  hipStream_t st = ctx().stream;
+  out.rows = in.cols;
+  out.cols = in.rows;
+  out.nnz = in.nnz;
+  out.binary = in.binary;
+  SS_TRY(out.ptr.alloc(out.rows + 1));
+  SS_TRY(out.idx.alloc(in.nnz));
+  SS_TRY(out.val.alloc(in.nnz));
+  const int64_t n = in.nnz;
+  DevBuf<int> hist;
+  SS_TRY(hist.alloc(out.rows + 1));
+  SS_HIP(hipMemsetAsync(hist.p, 0, (out.rows + 1) * sizeof(int), st));
+  if (n == 0) {
+    SS_HIP(hipMemsetAsync(out.ptr.p, 0, (out.rows + 1) * sizeof(int), st));
+    return SS_OK;
+  }
+  DevBuf<int> rowid, iota, keys_out, perm;
+  SS_TRY(rowid.alloc(n));
+  SS_TRY(iota.alloc(n));
+  SS_TRY(keys_out.alloc(n));
+  SS_TRY(perm.alloc(n));
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for(in.rows * 64, 256)), dim3(256), 0, st, in.ptr.p, in.rows,
+                     rowid.p, iota.p);
+  SS_LAUNCH_CHECK();
+  int bits = 1;
+  while ((1LL << bits) < in.cols && bits < 32) ++bits;
+  size_t bytes = 0;
+  SS_HIP(rocprim::radix_sort_pairs(nullptr, bytes, in.idx.p, keys_out.p, iota.p, perm.p, (size_t)n, 0u,
+                                   (unsigned)bits, st));
+  DevBuf<unsigned char> tmp;
+  SS_TRY(tmp.alloc(bytes));
+  SS_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, in.idx.p, keys_out.p, iota.p, perm.p, (size_t)n, 0u,
+                                   (unsigned)bits, st));
+  hipLaunchKernelGGL(histogram_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, in.idx.p, n, hist.p);
+  SS_LAUNCH_CHECK();
+  SS_TRY(exclusive_scan_int(hist.p, out.ptr.p, out.rows));
+  hipLaunchKernelGGL(gather_transpose_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, st, perm.p, rowid.p,
+                     in.val.p, n, out.idx.p, out.val.p);
+  SS_LAUNCH_CHECK();
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ CSR -> chunked SELL-64 with 16-bit local indices
+// one wave per (chunk, slice): lane = row; width = max entries of the 64 rows inside the chunk, in quads
+__global__ void sell_width_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, int64_t rows, int KC,
+                                  int nslices, int nchunks, int* __restrict__ widthq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= (int64_t)nslices * nchunks) return;
+  const int c = (int)(wave / nslices), s = (int)(wave % nslices);
+  const int64_t r = (int64_t)s * 64 + lane;
+  int n = 0;
+  if (r < rows) {
+    int lo = ptr[r], hi = ptr[r + 1];
+    const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
+    int a = lo, b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
+    const int first = a;
+    b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
+    n = a - first;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(n, o); n = t > n ? t : n; }
+  if (lane == 0) widthq[wave] = (n + 3) >> 2;
+}
+
+template <class T>
+__global__ void sell_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
+                                 int64_t rows, int KC, int nslices, int nchunks, const int* __restrict__ off,
+                                 unsigned short* __restrict__ sidx, T* __restrict__ sval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= (int64_t)nslices * nchunks) return;
+  const int c = (int)(wave / nslices), s = (int)(wave % nslices);
+  const int64_t r = (int64_t)s * 64 + lane;
+  int first = 0, n = 0;
+  const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
+  if (r < rows) {
+    int lo = ptr[r], hi = ptr[r + 1];
+    int a = lo, b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
+    first = a;
+    b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
+    n = a - first;
+  }
+  const int o = off[wave], oe = off[wave + 1];
+  for (int u = o; u < oe; ++u) {
+    const int64_t base = ((int64_t)u * 64 + lane) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = (u - o) * 4 + e;
+      const bool in = p < n;
+      sidx[base + e] = in ? (unsigned short)(idx[first + p] - k0) : (unsigned short)KC;
+      if (sval) sval[base + e] = in ? val[first + p] : T(0);
+    }
+  }
+}
+
+template <class T>
+int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
+  hipStream_t st = ctx().stream;
+  if (KCmax < 1 || KCmax > 65535) return fail(SS_EINVAL, "SELL chunk size out of range");
+  out.rows = in.rows;
+  out.cols = in.cols;
+  out.binary = in.binary;
+  out.KC = (int)((in.cols <= KCmax) ? (in.cols > 0 ? in.cols : 1) : KCmax);
+  out.nchunks = (int)(in.cols > 0 ? ceil_div(in.cols, out.KC) : 1);
+  out.nslices = (int)ceil_div(in.rows, 64);
+  const int64_t nws = (int64_t)out.nslices * out.nchunks;
+  SS_TRY(out.off.alloc(nws + 1));
+  if (nws == 0) {
+    SS_HIP(hipMemsetAsync(out.off.p, 0, sizeof(int), st));
+    out.nquads = 0;
+    SS_TRY(out.idx.alloc(0));
+    SS_TRY(out.val.alloc(0));
+    return SS_OK;
+  }
+  DevBuf<int> widthq;
+  SS_TRY(widthq.alloc(nws));
+  hipLaunchKernelGGL(sell_width_kernel, dim3((unsigned)ceil_div(nws * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p,
+                     in.rows, out.KC, out.nslices, out.nchunks, widthq.p);
+  SS_LAUNCH_CHECK();
+  SS_TRY(exclusive_scan_int(widthq.p, out.off.p, nws));
+  int nq = 0;
+  SS_TRY(read_int(out.off.p + nws, &nq));
+  if (nq < 0 || (int64_t)nq * 256 >= (1LL << 40)) return fail(SS_EUNSUPPORTED, "SELL storage too large");
+  out.nquads = nq;
+  SS_TRY(out.idx.alloc((size_t)nq * 256));
+  if (!out.binary) SS_TRY(out.val.alloc((size_t)nq * 256));
+  else out.val.release();
+  hipLaunchKernelGGL(sell_fill_kernel<T>, dim3((unsigned)ceil_div(nws * 64, 256)), dim3(256), 0, st, in.ptr.p,
+                     in.idx.p, in.val.p, in.rows, out.KC, out.nslices, out.nchunks, out.off.p, out.idx.p,
+                     out.binary ? (T*)nullptr : out.val.p);
+  SS_LAUNCH_CHECK();
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ degrees + transposes of a graph
+template <class T>
+__global__ void degree_kernel(const int* __restrict__ pa, const int* __restrict__ pb, int64_t n, int* __restrict__ k,
+                              T* __restrict__ inv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int d = pa[i + 1] - pa[i];
+    if (pb) d += pb[i + 1] - pb[i];
+    k[i] = d;
+    inv[i] = d > 0 ? T(1) / T(d) : T(0);  // spread's Inf/NaN -> 0 rule (src/core.jl:367-368)
+  }
+}
+
+template <class T>
+int graph_finalize(Graph<T>& g) {
+  hipStream_t st = ctx().stream;
+  SS_TRY(csr_transpose(g.Xs, g.XsT));
+  SS_TRY(csr_transpose(g.Ys, g.YsT));
+  SS_TRY(g.kf.alloc(g.nf));
+  SS_TRY(g.ks.alloc(g.ns));
+  SS_TRY(g.kt.alloc(g.nt));
+  SS_TRY(g.inv_kf.alloc(g.nf));
+  SS_TRY(g.inv_ks.alloc(g.ns));
+  SS_TRY(g.inv_kt.alloc(g.nt));
+  // kf: sources per feature; ks: features + targets per source; kt: sources per target
+  if (g.nf > 0) {
+    hipLaunchKernelGGL(degree_kernel<T>, dim3(grid_for(g.nf, 256)), dim3(256), 0, st, g.XsT.ptr.p, (const int*)nullptr,
+                       g.nf, g.kf.p, g.inv_kf.p);
+    SS_LAUNCH_CHECK();
+  }
+  if (g.ns > 0) {
+    hipLaunchKernelGGL(degree_kernel<T>, dim3(grid_for(g.ns, 256)), dim3(256), 0, st, g.Xs.ptr.p, g.Ys.ptr.p, g.ns,
+                       g.ks.p, g.inv_ks.p);
+    SS_LAUNCH_CHECK();
+  }
+  if (g.nt > 0) {
+    hipLaunchKernelGGL(degree_kernel<T>, dim3(grid_for(g.nt, 256)), dim3(256), 0, st, g.YsT.ptr.p, (const int*)nullptr,
+                       g.nt, g.kt.p, g.inv_kt.p);
+    SS_LAUNCH_CHECK();
+  }
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
+template <class T>
+int graph_finalize_general(Graph<T>& g) {
+  hipStream_t st = ctx().stream;
+  const int64_t n = g.ns;
+  SS_TRY(g.kf.alloc(n));
+  SS_TRY(g.inv_kf.alloc(n));
+  SS_TRY(g.ks.alloc(n));
+  SS_TRY(g.inv_ks.alloc(n));
+  SS_TRY(g.kt.alloc(g.nt));
+  SS_TRY(g.inv_kt.alloc(g.nt));
+  if (n > 0) {
+    hipLaunchKernelGGL(degree_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, st, g.XsT.ptr.p, (const int*)nullptr, n,
+                       g.kf.p, g.inv_kf.p);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(degree_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, st, g.XsT.ptr.p, (const int*)nullptr, n,
+                       g.ks.p, g.inv_ks.p);
+    SS_LAUNCH_CHECK();
+  }
+  if (g.nt > 0) {
+    hipLaunchKernelGGL(degree_kernel<T>, dim3(grid_for(g.nt, 256)), dim3(256), 0, st, g.YsT.ptr.p, (const int*)nullptr,
+                       g.nt, g.kt.p, g.inv_kt.p);
+    SS_LAUNCH_CHECK();
+  }
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
+#define SS_INSTANTIATE(T)                                                                                      \
+  template int csr_from_user<T>(int64_t, int64_t, const int64_t*, const int32_t*, const T*, int, int, DevCsr<T>&); \
+  template int csr_from_dense<T>(const T*, int64_t, int64_t, int64_t, bool, T, bool, int, DevCsr<T>&);         \
+  template int csr_transpose<T>(const DevCsr<T>&, DevCsr<T>&);                                                 \
+  template int sell_build<T>(const DevCsr<T>&, int, DevSell<T>&);                                              \
+  template int graph_finalize<T>(Graph<T>&);                                                                   \
+  template int graph_finalize_general<T>(Graph<T>&);
+SS_INSTANTIATE(float)
+SS_INSTANTIATE(double)
+
+}  // namespace ss

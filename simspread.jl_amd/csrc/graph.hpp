@@ -1,0 +1,120 @@
+// Device-resident sparse operands of the resource-spreading pass.
+//
+//   DevCsr   plain CSR, 4-byte row pointers and column indices (SURVEY.md 8d byte model)
+//   DevSell  the same matrix re-cut for the wide W*R kernel: rows in slices of 64 (one
+//            lane per row), columns in chunks of KC (one LDS tile of R per chunk),
+//            chunk-local 16-bit column indices, four entries per lane per load
+//   Graph    the blocks Xq, Xs, Ys of construct's adjacency (src/core.jl:165-187), their
+//            transposes, and the count degrees of B (src/core.jl:365-371)
+#pragma once
+#include "common.hpp"
+
+namespace ss {
+
+template <class T>
+struct DevCsr {
+  int64_t rows = 0, cols = 0, nnz = 0;
+  DevBuf<int> ptr;   // rows+1
+  DevBuf<int> idx;   // nnz, sorted within a row
+  DevBuf<T> val;     // nnz
+  bool binary = false;  // every stored value == 1
+};
+
+template <class T>
+struct DevSell {
+  int64_t rows = 0, cols = 0;
+  int KC = 0;          // columns per chunk (<= 65535); local index KC is the zero sentinel
+  int nchunks = 0;
+  int nslices = 0;     // ceil(rows / 64)
+  int64_t nquads = 0;  // total storage in units of 64 lanes x 4 entries
+  bool binary = false;
+  DevBuf<int> off;              // [nchunks*nslices + 1] quad offsets, chunk-major
+  DevBuf<unsigned short> idx;   // [nquads][64][4]
+  DevBuf<T> val;                // [nquads][64][4] unless binary
+};
+
+template <class T>
+struct Graph {
+  int64_t nq = 0, ns = 0, nf = 0, nt = 0;
+  bool general = false;  // built by ss_graph_create_general: only Xq, XsT, YsT and kf == ks are set
+  DevCsr<T> Xq;    // nq x nf
+  DevCsr<T> Xs;    // ns x nf
+  DevCsr<T> XsT;   // nf x ns
+  DevCsr<T> Ys;    // ns x nt
+  DevCsr<T> YsT;   // nt x ns   (the W of F = W*R)
+  DevBuf<int> kf, ks, kt;           // count degrees in B
+  DevBuf<T> inv_kf, inv_ks, inv_kt; // 1/k, 0 where k == 0   (the Inf/NaN -> 0 rule)
+  // stage-2 operand, built lazily per tile width
+  DevSell<T> W;
+  int W_qt = 0;
+  DevBuf<T> Tws;  // workspace: rows of the transfer block T between stage 1 and stage 2
+};
+
+template <class T>
+struct SpMat {
+  DevCsr<T> csr;
+  DevSell<T> sell;
+  int sell_qt = 0;
+};
+
+// ---- assemble.hip
+template <class T>
+int csr_from_user(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const T* val,
+                  int index_base, int mem, DevCsr<T>& out);
+template <class T>
+int csr_from_dense(const T* S, int64_t rows, int64_t cols, int64_t ld, bool apply_cutoff, T alpha,
+                   bool weighted, int mem, DevCsr<T>& out);
+template <class T>
+int csr_transpose(const DevCsr<T>& in, DevCsr<T>& out);
+template <class T>
+int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out);
+template <class T>
+int graph_finalize(Graph<T>& g);  // transposes + degrees
+template <class T>
+int graph_finalize_general(Graph<T>& g);  // degrees = row counts of B (held in XsT)
+
+// ---- kernels.hip (launch wrappers; everything is enqueued on ctx().stream)
+template <class T>
+struct CsrView {
+  const int* ptr;
+  const int* idx;
+  const T* val;
+};
+template <class T>
+inline CsrView<T> view(const DevCsr<T>& m) { return CsrView<T>{m.ptr.p, m.idx.p, m.val.p}; }
+
+template <class T>
+int launch_cutoff(const T* X, int64_t rows, int64_t cols, int64_t ld, T alpha, bool weighted, T* out, int64_t ldo);
+template <class T>
+int launch_row_degree(const T* G, int64_t rows, int64_t cols, int64_t ld, int* deg);
+template <class T>
+int launch_spread_dense(const T* G, int64_t rows, int64_t cols, int64_t ld, const int* deg, T* W, int64_t ldw);
+
+// stage 1: T[r][j] = inv2[j] * sum_terms sum_a L[r,a] * inv1[a] * Mt[a][j]   (rows row_begin..+nrows)
+template <class T>
+int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevCsr<T>* Mt[2],
+                    const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld);
+// leave-one-out flavour: row i of X against X' with the rank-1 degree corrections
+template <class T>
+int launch_transfer_loo(const DevCsr<T>& X, const DevCsr<T>& XT, const int* kf, const int* ks,
+                        int64_t i_begin, int64_t nrows, T* out, int64_t ld);
+
+// stage 2, wide: F[b][m] = sum_k W[m][k] * R[b][k]   (R, F "column-major": one row of length K / M per b)
+template <class T>
+int sell_tile_width();  // QT for this T
+template <class T>
+int sell_max_chunk(int qt);
+template <class T>
+int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T* F, int64_t ldf,
+                     const int* clean_deg);
+// stage 2, narrow (B <= 64): F[m][b] = sum_k W[m][k] * R[k][b]   (row-major operands, CSR streamed once)
+template <class T>
+int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
+
+template <class T>
+int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout);
+// clean! for leave-one-out rows: target t whose only edge belongs to query i
+template <class T>
+int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, int64_t nrows, T* out, int64_t ld);
+
+}  // namespace ss

@@ -1,0 +1,540 @@
+// Hand-written gfx950 kernels of the SimSpread resource-spreading pass.
+//
+//   transfer_kernel      stage 1: one row of the transfer block T = (L D1^-1) Mt D2^-1 per
+//                        workgroup, accumulated in LDS (the sparse x sparse -> dense product
+//                        hidden in the reference's W*W, src/core.jl:413)
+//   spmm_sell_kernel     stage 2, wide: F = W*R with an LDS-resident tile of QT columns of R,
+//                        one lane per row of W, chunk-local 16-bit indices (the A*W^2 row
+//                        gather of src/core.jl:413,421 restricted to the Nq x Nt corner)
+//   spmm_csr_narrow      stage 2, narrow (B <= 64): CSR streamed once from HBM, wave per row,
+//                        __shfl broadcast of (index,value) and __shfl_xor reduction
+//   cutoff / row_degree / spread_dense   the element-wise pieces (src/core.jl:37-43,365-371,
+//                        src/graphs.jl:9-11)
+//
+// Wavefront = 64 lanes everywhere.  No float atomics touch global memory; stage 1 uses LDS
+// float atomics inside one workgroup only.
+#include "graph.hpp"
+
+namespace ss {
+
+static inline int grid_1d(int64_t work, int block, int cap = 256 * 16) {
+  int64_t g = ceil_div(work, block);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+#define SS_LAUNCH_CHECK()                                                             \
+  do {                                                                                \
+    hipError_t _e = hipGetLastError();                                                \
+    if (_e != hipSuccess)                                                             \
+      return fail(SS_EHIP, "%s:%d kernel launch: %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+  } while (0)
+
+// ============================================================== element-wise
+template <class T>
+__global__ void cutoff_kernel(const T* __restrict__ X, int64_t rows, int64_t cols, int64_t ld, T alpha,
+                              int weighted, T* __restrict__ out, int64_t ldo) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i / rows, r = i - c * rows;
+    const T x = X[r + c * ld];
+    out[r + c * ldo] = (x >= alpha) ? (weighted ? x : T(1)) : T(0);
+  }
+}
+
+template <class T>
+int launch_cutoff(const T* X, int64_t rows, int64_t cols, int64_t ld, T alpha, bool weighted, T* out, int64_t ldo) {
+  if (rows * cols == 0) return SS_OK;
+  hipLaunchKernelGGL(cutoff_kernel<T>, dim3(grid_1d(rows * cols, 256)), dim3(256), 0, ctx().stream, X, rows,
+                     cols, ld, alpha, weighted ? 1 : 0, out, ldo);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// k(G): one thread per row, lanes walk the same column together (coalesced in column-major)
+template <class T>
+__global__ void row_degree_kernel(const T* __restrict__ G, int64_t rows, int64_t cols, int64_t ld,
+                                  int* __restrict__ deg) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    int n = 0;
+    for (int64_t c = 0; c < cols; ++c) n += (G[r + c * ld] != T(0)) ? 1 : 0;
+    deg[r] = n;
+  }
+}
+
+template <class T>
+int launch_row_degree(const T* G, int64_t rows, int64_t cols, int64_t ld, int* deg) {
+  if (rows == 0) return SS_OK;
+  hipLaunchKernelGGL(row_degree_kernel<T>, dim3(grid_1d(rows, 64)), dim3(64), 0, ctx().stream, G, rows, cols,
+                     ld, deg);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+template <class T>
+__global__ void spread_dense_kernel(const T* __restrict__ G, int64_t rows, int64_t cols, int64_t ld,
+                                    const int* __restrict__ deg, T* __restrict__ W, int64_t ldw) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i / rows, r = i - c * rows;
+    const int d = deg[r];
+    W[r + c * ldw] = d > 0 ? G[r + c * ld] / T(d) : T(0);
+  }
+}
+
+template <class T>
+int launch_spread_dense(const T* G, int64_t rows, int64_t cols, int64_t ld, const int* deg, T* W, int64_t ldw) {
+  if (rows * cols == 0) return SS_OK;
+  hipLaunchKernelGGL(spread_dense_kernel<T>, dim3(grid_1d(rows * cols, 256)), dim3(256), 0, ctx().stream, G,
+                     rows, cols, ld, deg, W, ldw);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ============================================================== stage 1: transfer rows
+template <class T>
+struct TransferArgs {
+  int nterms;
+  CsrView<T> L[2];
+  const T* inv1[2];
+  CsrView<T> M[2];
+  const T* inv2;
+  const int* kf;  // LOO: integer degrees
+  const int* ks;
+  int64_t row_begin;
+  int64_t nj;
+  int jc;  // columns of T held in LDS at a time
+  T* out;
+  int64_t ld;
+};
+
+__device__ __forceinline__ int lower_bound_dev(const int* __restrict__ a, int lo, int hi, int key) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// One workgroup per row r of L.  acc[j] (LDS) collects sum_a L[r,a]*inv1[a]*Mt[a][j]; every wave
+// takes every nwaves-th neighbour a of r and streams row a of Mt with coalesced loads.
+template <class T, bool LOO>
+__global__ void __launch_bounds__(256) transfer_kernel(TransferArgs<T> p) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* acc = reinterpret_cast<T*>(smem_raw);
+  unsigned* bits = reinterpret_cast<unsigned*>(acc + p.jc);  // LOO only: j has the dropped feature
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int64_t r = blockIdx.x;
+  const int64_t gr = p.row_begin + r;
+  const bool chunked = p.nj > p.jc;
+
+  for (int64_t j0 = 0; j0 < p.nj; j0 += p.jc) {
+    const int jn = (int)((p.nj - j0 < p.jc) ? (p.nj - j0) : p.jc);
+    for (int j = tid; j < jn; j += blockDim.x) acc[j] = T(0);
+    if (LOO)
+      for (int j = tid; j < (jn + 31) / 32; j += blockDim.x) bits[j] = 0u;
+    __syncthreads();
+
+    for (int t = 0; t < p.nterms; ++t) {
+      const CsrView<T> L = p.L[t];
+      const CsrView<T> M = p.M[t];
+      const int lb = L.ptr[gr], le = L.ptr[gr + 1];
+      for (int q = lb + wave; q < le; q += nwaves) {
+        const int a = L.idx[q];
+        const T lv = L.val[q];
+        T coef;
+        if (LOO) {
+          if (a == (int)gr) continue;  // the feature named after the query is not in the graph
+          const int d = p.kf[a] - 1;   // the query leaves every feature column it touched
+          coef = d > 0 ? lv * (T(1) / T(d)) : T(0);
+        } else {
+          coef = lv * p.inv1[t][a];
+        }
+        if (coef == T(0)) continue;
+        int mb = M.ptr[a], me = M.ptr[a + 1];
+        if (chunked) {
+          mb = lower_bound_dev(M.idx, mb, me, (int)j0);
+          me = lower_bound_dev(M.idx, mb, me, (int)(j0 + jn));
+        }
+        for (int x = mb + lane; x < me; x += 64) {
+          const int j = M.idx[x] - (int)j0;
+          atomicAdd(&acc[j], coef * M.val[x]);
+        }
+      }
+    }
+    if (LOO) {
+      // sources that own the dropped feature column f_i: their degree is one lower in this fold
+      const CsrView<T> M = p.M[0];
+      int mb = M.ptr[gr], me = M.ptr[gr + 1];
+      if (chunked) {
+        mb = lower_bound_dev(M.idx, mb, me, (int)j0);
+        me = lower_bound_dev(M.idx, mb, me, (int)(j0 + jn));
+      }
+      for (int x = mb + tid; x < me; x += blockDim.x) {
+        const int j = M.idx[x] - (int)j0;
+        atomicOr(&bits[j >> 5], 1u << (j & 31));
+      }
+    }
+    __syncthreads();
+
+    T* orow = p.out + r * p.ld + j0;
+    for (int j = tid; j < jn; j += blockDim.x) {
+      T z;
+      if (LOO) {
+        const int d = p.ks[j0 + j] - (int)((bits[j >> 5] >> (j & 31)) & 1u);
+        z = (d > 0 && (j0 + j) != gr) ? acc[j] * (T(1) / T(d)) : T(0);
+      } else {
+        z = acc[j] * p.inv2[j0 + j];
+      }
+      orow[j] = z;
+    }
+    __syncthreads();
+  }
+}
+
+template <class T>
+static int transfer_chunk(int64_t nj, bool loo) {
+  // LDS budget per workgroup: keep >= 2 workgroups per CU when the row is long
+  const int64_t budget = 64 * 1024;
+  int64_t jc = budget / (int64_t)sizeof(T);
+  if (loo) jc = (budget * 32) / (32 * (int64_t)sizeof(T) + 4);
+  jc &= ~63LL;
+  if (nj <= jc) jc = (nj + 63) & ~63LL;
+  return (int)jc;
+}
+
+template <class T>
+int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevCsr<T>* Mt[2],
+                    const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld) {
+  if (nrows <= 0 || nj <= 0) return SS_OK;
+  TransferArgs<T> p{};
+  p.nterms = nterms;
+  for (int t = 0; t < nterms; ++t) {
+    p.L[t] = view(*L[t]);
+    p.M[t] = view(*Mt[t]);
+    p.inv1[t] = inv1[t];
+  }
+  p.inv2 = inv2;
+  p.row_begin = row_begin;
+  p.nj = nj;
+  p.jc = transfer_chunk<T>(nj, false);
+  p.out = out;
+  p.ld = ld;
+  const size_t lds = (size_t)p.jc * sizeof(T);
+  hipLaunchKernelGGL((transfer_kernel<T, false>), dim3((unsigned)nrows), dim3(256), lds, ctx().stream, p);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+template <class T>
+int launch_transfer_loo(const DevCsr<T>& X, const DevCsr<T>& XT, const int* kf, const int* ks,
+                        int64_t i_begin, int64_t nrows, T* out, int64_t ld) {
+  if (nrows <= 0) return SS_OK;
+  TransferArgs<T> p{};
+  p.nterms = 1;
+  p.L[0] = view(X);
+  p.M[0] = view(XT);
+  p.kf = kf;
+  p.ks = ks;
+  p.row_begin = i_begin;
+  p.nj = X.rows;
+  p.jc = transfer_chunk<T>(p.nj, true);
+  p.out = out;
+  p.ld = ld;
+  const size_t lds = (size_t)p.jc * sizeof(T) + (size_t)((p.jc + 31) / 32) * 4;
+  hipLaunchKernelGGL((transfer_kernel<T, true>), dim3((unsigned)nrows), dim3(256), lds, ctx().stream, p);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ============================================================== stage 2, wide: SELL x LDS tile
+template <class T, int QT>
+struct alignas(sizeof(T) * QT) Vec {
+  T v[QT];
+};
+
+template <class T>
+struct SellArgs {
+  const int* off;
+  const unsigned short* idx;
+  const T* val;
+  int nslices, nchunks, KC;
+  int64_t K, M, B;
+  const T* R;
+  int64_t ldr;
+  T* F;
+  int64_t ldf;
+  const int* clean_deg;
+};
+
+constexpr int SELL_THREADS = 1024;
+
+// Workgroup = QT columns of R (QT queries).  Per chunk of KC columns of W: the tile
+// R[b0..b0+QT)[k0..k0+KC) sits in LDS as [k][QT] so that one ds_read_b128 fetches the QT
+// operands of a non-zero; waves walk the slices, lane = row of W, no cross-lane reduction.
+template <class T, int QT, bool BIN>
+__global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  using V = Vec<T, QT>;
+  V* tile = reinterpret_cast<V*>(smem_raw);  // [KC + 1]; entry KC stays zero (padding target)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int64_t b0 = (int64_t)blockIdx.x * QT;
+
+  for (int c = 0; c < a.nchunks; ++c) {
+    const int64_t k0 = (int64_t)c * a.KC;
+    const int kn = (int)((a.K - k0 < a.KC) ? (a.K - k0) : a.KC);
+    if (c) __syncthreads();
+    for (int k = tid; k <= a.KC; k += blockDim.x) {
+      V v;
+#pragma unroll
+      for (int q = 0; q < QT; ++q)
+        v.v[q] = (k < kn && b0 + q < a.B) ? a.R[(b0 + q) * a.ldr + k0 + k] : T(0);
+      tile[k] = v;
+    }
+    __syncthreads();
+
+    const int* off = a.off + (int64_t)c * a.nslices;
+    const bool last = (c == a.nchunks - 1);
+    for (int s = wave; s < a.nslices; s += nwaves) {
+      const int o = __builtin_amdgcn_readfirstlane(off[s]);
+      const int oe = __builtin_amdgcn_readfirstlane(off[s + 1]);
+      T acc[QT];
+#pragma unroll
+      for (int q = 0; q < QT; ++q) acc[q] = T(0);
+      const ushort4* ip = reinterpret_cast<const ushort4*>(a.idx) + (int64_t)o * 64 + lane;
+      const Vec<T, 4>* vp = reinterpret_cast<const Vec<T, 4>*>(a.val) + (int64_t)o * 64 + lane;
+#pragma unroll 2
+      for (int u = o; u < oe; ++u, ip += 64, vp += 64) {
+        const ushort4 iv = *ip;
+        const V t0 = tile[iv.x], t1 = tile[iv.y], t2 = tile[iv.z], t3 = tile[iv.w];
+        if (BIN) {
+#pragma unroll
+          for (int q = 0; q < QT; ++q) acc[q] += (t0.v[q] + t1.v[q]) + (t2.v[q] + t3.v[q]);
+        } else {
+          const Vec<T, 4> w = *vp;
+#pragma unroll
+          for (int q = 0; q < QT; ++q) {
+            acc[q] = fma(w.v[0], t0.v[q], acc[q]);
+            acc[q] = fma(w.v[1], t1.v[q], acc[q]);
+            acc[q] = fma(w.v[2], t2.v[q], acc[q]);
+            acc[q] = fma(w.v[3], t3.v[q], acc[q]);
+          }
+        }
+      }
+      const int64_t m = (int64_t)s * 64 + lane;
+      if (m < a.M) {
+        const bool flag = last && a.clean_deg != nullptr && a.clean_deg[m] == 0;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+          if (b0 + q < a.B) {
+            T* f = a.F + (b0 + q) * a.ldf + m;
+            T r = acc[q];
+            if (c) r += *f;
+            *f = flag ? T(-99) : r;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <> int sell_tile_width<float>() { return 4; }
+template <> int sell_tile_width<double>() { return 2; }
+
+template <class T>
+int sell_max_chunk(int qt) {
+  // (KC + 1) * qt * sizeof(T) <= 160 KiB and KC <= 65535 (16-bit local index, KC is the sentinel)
+  int64_t kc = (int64_t)(160 * 1024) / ((int64_t)qt * (int64_t)sizeof(T)) - 1;
+  if (kc > 65535) kc = 65535;
+  return (int)kc;
+}
+
+template <class T>
+int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T* F, int64_t ldf,
+                     const int* clean_deg) {
+  if (B <= 0 || W.rows <= 0) return SS_OK;
+  constexpr int QT = sizeof(T) == 4 ? 4 : 2;
+  SellArgs<T> a{};
+  a.off = W.off.p;
+  a.idx = W.idx.p;
+  a.val = W.val.p;
+  a.nslices = W.nslices;
+  a.nchunks = W.nchunks;
+  a.KC = W.KC;
+  a.K = W.cols;
+  a.M = W.rows;
+  a.B = B;
+  a.R = R;
+  a.ldr = ldr;
+  a.F = F;
+  a.ldf = ldf;
+  a.clean_deg = clean_deg;
+  const size_t lds = (size_t)(W.KC + 1) * QT * sizeof(T);
+  const unsigned grid = (unsigned)ceil_div(B, QT);
+  static bool attr_set[2] = {false, false};
+  if (W.binary) {
+    if (!attr_set[0]) {
+      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set[0] = true;
+    }
+    hipLaunchKernelGGL((spmm_sell_kernel<T, QT, true>), dim3(grid), dim3(SELL_THREADS), lds, ctx().stream, a);
+  } else {
+    if (!attr_set[1]) {
+      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set[1] = true;
+    }
+    hipLaunchKernelGGL((spmm_sell_kernel<T, QT, false>), dim3(grid), dim3(SELL_THREADS), lds, ctx().stream, a);
+  }
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ============================================================== stage 2, narrow: CSR streamed once
+// Wave per row.  Each lane loads one (index,value) of the row (coalesced 256-B requests), then the
+// wave replays them: LPN lanes share a non-zero and fetch B contiguous values of R's row, 64/LPN
+// non-zeros per step; partial sums of the 64/LPN groups are folded with __shfl_xor.
+template <class T, int VEC, int LPN>
+__global__ void __launch_bounds__(256) spmm_csr_narrow_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                              const T* __restrict__ val, int64_t M,
+                                                              const T* __restrict__ R, int64_t ldr, int B,
+                                                              T* __restrict__ F, int64_t ldf) {
+  constexpr int NPS = 64 / LPN;  // non-zeros per step
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPN;
+  const int c0 = (lane % LPN) * VEC;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t m = wave0; m < M; m += nwaves) {
+    const int b = ptr[m], e = ptr[m + 1];
+    T acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = T(0);
+    for (int base = b; base < e; base += 64) {
+      const int x = base + lane;
+      const int kk = x < e ? idx[x] : 0;
+      const T vv = x < e ? val[x] : T(0);
+      const int cnt = (e - base < 64) ? (e - base) : 64;
+      if (LPN == 1) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+          if (i < B) acc[i] = fma(vv, R[(int64_t)kk * ldr + i], acc[i]);
+      } else {
+        for (int i = 0; i < cnt; i += NPS) {
+          const int src = i + g;
+          const int k = __shfl(kk, src);
+          const T v = __shfl(vv, src);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (c0 + j < B) acc[j] = fma(v, R[(int64_t)k * ldr + c0 + j], acc[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = LPN; o < 64; o <<= 1)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], o);
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (c0 + i < B) F[m * ldf + c0 + i] = acc[i];
+    }
+  }
+}
+
+template <class T>
+int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf) {
+  if (W.rows <= 0 || B <= 0) return SS_OK;
+  if (B > 64) return fail(SS_EINVAL, "narrow SpMM serves B <= 64 (got %d)", B);
+  const int block = 256;
+  const int grid = grid_1d(W.rows * 64, block, 256 * 32);
+#define SS_NARROW(VEC, LPN)                                                                          \
+  hipLaunchKernelGGL((spmm_csr_narrow_kernel<T, VEC, LPN>), dim3(grid), dim3(block), 0, ctx().stream, \
+                     W.ptr.p, W.idx.p, W.val.p, W.rows, R, ldr, B, F, ldf)
+  if (B == 1) SS_NARROW(1, 1);
+  else if (B == 2) SS_NARROW(2, 1);
+  else if (B <= 4) SS_NARROW(4, 1);
+  else if (B <= 8) SS_NARROW(4, 2);
+  else if (B <= 16) SS_NARROW(4, 4);
+  else if (B <= 32) SS_NARROW(4, 8);
+  else SS_NARROW(4, 16);
+#undef SS_NARROW
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ============================================================== transpose (layout conversion)
+// in: rows x cols, element (r,c) at in[r*ldin + c]; out: (c,r) at out[c*ldout + r]
+template <class T>
+__global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in, int64_t rows, int64_t cols,
+                                                        int64_t ldin, T* __restrict__ out, int64_t ldout) {
+  __shared__ T tile[64][65];
+  const int64_t c0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[r * ldin + c] : T(0);
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) out[c * ldout + r] = tile[tx][i];
+  }
+}
+
+template <class T>
+int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout) {
+  if (rows <= 0 || cols <= 0) return SS_OK;
+  dim3 grid((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64));
+  hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, ctx().stream, in, rows, cols, ldin, out, ldout);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ============================================================== LOO clean! fix-up
+// In fold i target t has degree kt[t] - [Y[i,t] != 0] (src/core.jl:479): the kt == 0 columns are
+// flagged by the SpMM epilogue, here the columns whose single edge belongs to the query itself.
+template <class T>
+__global__ void loo_clean_fix_kernel(const int* __restrict__ tptr, const int* __restrict__ tidx,
+                                     const int* __restrict__ kt, int64_t nt, int64_t i_begin, int64_t nrows,
+                                     T* __restrict__ out, int64_t ld) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
+    if (kt[t] == 1) {
+      const int64_t s = tidx[tptr[t]];
+      if (s >= i_begin && s < i_begin + nrows) out[(s - i_begin) * ld + t] = T(-99);
+    }
+  }
+}
+
+template <class T>
+int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, int64_t nrows, T* out, int64_t ld) {
+  if (YsT.rows <= 0 || nrows <= 0) return SS_OK;
+  hipLaunchKernelGGL(loo_clean_fix_kernel<T>, dim3(grid_1d(YsT.rows, 256)), dim3(256), 0, ctx().stream,
+                     YsT.ptr.p, YsT.idx.p, kt, YsT.rows, i_begin, nrows, out, ld);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ============================================================== explicit instantiations
+#define SS_INSTANTIATE(T)                                                                                   \
+  template int launch_cutoff<T>(const T*, int64_t, int64_t, int64_t, T, bool, T*, int64_t);                 \
+  template int launch_row_degree<T>(const T*, int64_t, int64_t, int64_t, int*);                             \
+  template int launch_spread_dense<T>(const T*, int64_t, int64_t, int64_t, const int*, T*, int64_t);        \
+  template int launch_transfer<T>(int, const DevCsr<T>*[2], const T*[2], const DevCsr<T>*[2], const T*,     \
+                                  int64_t, int64_t, int64_t, T*, int64_t);                                  \
+  template int launch_transfer_loo<T>(const DevCsr<T>&, const DevCsr<T>&, const int*, const int*, int64_t,  \
+                                      int64_t, T*, int64_t);                                                \
+  template int sell_max_chunk<T>(int);                                                                      \
+  template int launch_spmm_sell<T>(const DevSell<T>&, const T*, int64_t, int64_t, T*, int64_t, const int*); \
+  template int launch_spmm_csr_narrow<T>(const DevCsr<T>&, const T*, int64_t, int, T*, int64_t);            \
+  template int launch_transpose<T>(const T*, int64_t, int64_t, int64_t, T*, int64_t);                       \
+  template int launch_loo_clean_fix<T>(const DevCsr<T>&, const int*, int64_t, int64_t, T*, int64_t);
+SS_INSTANTIATE(float)
+SS_INSTANTIATE(double)
+
+}  // namespace ss

@@ -1,0 +1,268 @@
+"""Device handles over the C ABI: the tri-partite graph (`DeviceGraph`) and the raw W*R
+operand (`DeviceSpMat`).  Inputs are numpy / scipy.sparse (host) or torch CUDA tensors
+(device, passed by ``data_ptr()``); outputs are numpy arrays or, when ``out`` is a torch CUDA
+tensor, written in place on the device.  Everything computes on the GPU through
+libsimspread_hip.so -- nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _suffix(dtype) -> str:
+    dt = np.dtype(dtype)
+    if dt == np.float32:
+        return "f32"
+    if dt == np.float64:
+        return "f64"
+    raise TypeError(f"dtype {dt} not supported (float32 / float64)")
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _csr_parts(m, dtype, shape=None):
+    """(ptr int64, idx int32, val dtype) numpy arrays of a scipy.sparse matrix, sorted indices."""
+    import scipy.sparse as sp
+    if m is None:
+        rows = shape[0]
+        return np.zeros(rows + 1, np.int64), np.zeros(0, np.int32), np.zeros(0, dtype)
+    m = sp.csr_matrix(m)
+    if shape is not None and m.shape != tuple(shape):
+        raise ValueError(f"block has shape {m.shape}, expected {tuple(shape)}")
+    if not m.has_sorted_indices:
+        m = m.sorted_indices()
+    m.sum_duplicates()
+    return (np.ascontiguousarray(m.indptr, dtype=np.int64), np.ascontiguousarray(m.indices, dtype=np.int32),
+            np.ascontiguousarray(m.data, dtype=dtype))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class DeviceGraph:
+    """``construct(...)`` on the device: blocks Xq (nq x nf), Xs (ns x nf), Ys (ns x nt) as CSR plus
+    transposes and count degrees (reference: src/core.jl:148-201,217-276,308-337,365-371)."""
+
+    def __init__(self, handle, dtype, general=False):
+        self._h = handle
+        self.dtype = np.dtype(dtype)
+        self._suf = _suffix(dtype)
+        self.general = general
+        info = (C.c_int64 * 7)()
+        L.check(L.load().ss_graph_info(self._h, info))
+        self.nq, self.ns, self.nf, self.nt, self.nnz_xq, self.nnz_xs, self.nnz_ys = [int(v) for v in info]
+
+    # ---------------------------------------------------------------- constructors
+    @classmethod
+    def from_sparse(cls, Xq, Xs, Ys, dtype=np.float32):
+        """Host CSR blocks (scipy.sparse or anything csr_matrix accepts).  Xq may be None (3-layer graph)."""
+        import scipy.sparse as sp
+        lib = L.lib()
+        Xs = sp.csr_matrix(Xs)
+        Ys = sp.csr_matrix(Ys)
+        ns, nf = Xs.shape
+        nt = Ys.shape[1]
+        if Ys.shape[0] != ns:
+            raise AssertionError("Labels and features have different number of source nodes")
+        nq = 0 if Xq is None else sp.csr_matrix(Xq).shape[0]
+        if Xq is not None and sp.csr_matrix(Xq).shape[1] != nf:
+            raise AssertionError("Number of features between test and training sets doesn't match")
+        q = _csr_parts(Xq, dtype, (nq, nf))
+        s = _csr_parts(Xs, dtype, (ns, nf))
+        y = _csr_parts(Ys, dtype, (ns, nt))
+        h = C.c_void_p()
+        fn = getattr(lib, f"ss_graph_create_csr_{_suffix(dtype)}")
+        L.check(fn(nq, ns, nf, nt, _ptr(q[0]), _ptr(q[1]), _ptr(q[2]), _ptr(s[0]), _ptr(s[1]), _ptr(s[2]),
+                   _ptr(y[0]), _ptr(y[1]), _ptr(y[2]), 0, L.SS_MEM_HOST, C.byref(h)))
+        return cls(h, dtype)
+
+    @classmethod
+    def from_dense(cls, Sq, Ss, Y, alpha: Optional[float] = None, weighted: bool = True, dtype=np.float32):
+        """Dense blocks; with ``alpha`` the featurize cutoff (src/core.jl:106-112) is applied on the
+        device while the CSR operands are assembled.  Arrays may be numpy (any order) or torch CUDA
+        tensors; they are read as column-major (a C-order array is passed as its transpose... no copy
+        is made for Fortran-order inputs)."""
+        lib = L.lib()
+        dt = np.dtype(dtype)
+
+        def prep(a, rows_expected=None):
+            # returns (pointer, ld, rows, cols, mem, keepalive) for a column-major view
+            if a is None:
+                return None, 1, 0, None, L.SS_MEM_HOST, None
+            if _is_torch(a):
+                import torch
+                want = torch.float32 if dt == np.float32 else torch.float64
+                t = a.to(want)
+                # column-major rows x cols == row-major cols x rows: need t.T contiguous
+                tt = t.t().contiguous()
+                return tt.data_ptr(), t.shape[0], t.shape[0], t.shape[1], L.SS_MEM_DEVICE, tt
+            arr = np.asfortranarray(np.asarray(a, dtype=dt))
+            if arr.ndim != 2:
+                raise ValueError("dense blocks must be matrices")
+            return arr.ctypes.data, max(arr.shape[0], 1), arr.shape[0], arr.shape[1], L.SS_MEM_HOST, arr
+
+        pq, ldq, nq, nfq, memq, kq = prep(Sq)
+        ps, lds, ns, nf, mems, ks_ = prep(Ss)
+        py, ldy, nsy, nt, memy, ky = prep(Y)
+        if nsy != ns:
+            raise AssertionError("Labels and features have different number of source nodes")
+        if Sq is not None and nfq != nf:
+            raise AssertionError("Number of features between test and training sets doesn't match")
+        mems_used = {m for m, a in ((memq, Sq), (mems, Ss), (memy, Y)) if a is not None}
+        if len(mems_used) != 1:
+            raise ValueError("dense blocks must all live on the host or all on the device")
+        mem = mems_used.pop()
+        h = C.c_void_p()
+        fn = getattr(lib, f"ss_graph_create_dense_{_suffix(dtype)}")
+        ctype = C.c_float if dt == np.float32 else C.c_double
+        L.check(fn(nq, ns, nf, nt, pq, ldq, ps, lds, py, ldy, 0 if alpha is None else 1,
+                   ctype(0.0 if alpha is None else alpha), 1 if weighted else 0, mem, C.byref(h)))
+        del kq, ks_, ky
+        return cls(h, dtype)
+
+    @classmethod
+    def general(cls, A_rows, B, B_cols_T, dtype=np.float64):
+        """predict for caller-built A, B (src/core.jl:402-425): A_rows = A[rows, :], B, B_cols_T = B[:, cols]'."""
+        import scipy.sparse as sp
+        lib = L.lib()
+        A_rows, B, Wt = sp.csr_matrix(A_rows), sp.csr_matrix(B), sp.csr_matrix(B_cols_T)
+        n = B.shape[0]
+        if B.shape[1] != n or A_rows.shape[1] != n or Wt.shape[1] != n:
+            raise ValueError("general graph: inconsistent shapes")
+        l, b, w = _csr_parts(A_rows, dtype), _csr_parts(B, dtype), _csr_parts(Wt, dtype)
+        h = C.c_void_p()
+        fn = getattr(lib, f"ss_graph_create_general_{_suffix(dtype)}")
+        L.check(fn(n, A_rows.shape[0], Wt.shape[0], _ptr(l[0]), _ptr(l[1]), _ptr(l[2]), _ptr(b[0]), _ptr(b[1]),
+                   _ptr(b[2]), _ptr(w[0]), _ptr(w[1]), _ptr(w[2]), 0, L.SS_MEM_HOST, C.byref(h)))
+        return cls(h, dtype, general=True)
+
+    # ---------------------------------------------------------------- queries
+    def degrees(self):
+        """(kf, ks, kt): count degrees of the query-free graph B (src/graphs.jl:9-11, src/core.jl:366)."""
+        kf, ks, kt = (np.zeros(n, np.int64) for n in (self.nf, self.ns, self.nt))
+        L.check(L.lib().ss_graph_degrees(self._h, _ptr(kf), _ptr(ks), _ptr(kt)))
+        return kf, ks, kt
+
+    def _run(self, fn_name, head_args, nrows, clean, out, layout):
+        lib = L.lib()
+        colmajor = (layout == "col")
+        lay = L.SS_LAYOUT_COLMAJOR if colmajor else L.SS_LAYOUT_ROWMAJOR
+        shape = (self.nt, nrows) if colmajor else (nrows, self.nt)  # as a C-order buffer
+        if out is None:
+            out = np.empty(shape, dtype=self.dtype)
+        if _is_torch(out):
+            if tuple(out.shape) != shape or not out.is_contiguous() or not out.is_cuda:
+                raise ValueError(f"out must be a contiguous CUDA tensor of shape {shape}")
+            if np.dtype(str(out.dtype).replace("torch.", "")) != self.dtype:
+                raise TypeError("out dtype does not match the graph precision")
+            ptr, mem = out.data_ptr(), L.SS_MEM_DEVICE
+        else:
+            if out.shape != shape or out.dtype != self.dtype or not out.flags.c_contiguous:
+                raise ValueError(f"out must be a C-contiguous {self.dtype} array of shape {shape}")
+            ptr, mem = out.ctypes.data, L.SS_MEM_HOST
+        fn = getattr(lib, f"{fn_name}_{self._suf}")
+        L.check(fn(self._h, *head_args, 1 if clean else 0, ptr, shape[1], lay, mem))
+        if colmajor and not _is_torch(out):
+            return out.T  # (nrows, nt) view, Fortran order -- what a Julia caller sees
+        return out
+
+    def predict(self, rows: str = "query", row_begin: int = 0, row_end: Optional[int] = None, clean: bool = False,
+                out=None, layout: str = "row"):
+        """Scores of rows [row_begin,row_end) of the query (or source) nodes against all targets
+        (predict, src/core.jl:402-425,446-466; clean! fused, src/core.jl:478-484)."""
+        kind = {"query": L.SS_ROWS_QUERY, "source": L.SS_ROWS_SOURCE}[rows]
+        limit = self.nq if rows == "query" else self.ns
+        row_end = limit if row_end is None else row_end
+        return self._run("ss_predict", (kind, row_begin, row_end), row_end - row_begin, clean, out, layout)
+
+    def predict_loo(self, i_begin: int = 0, i_end: Optional[int] = None, clean: bool = False, out=None,
+                    layout: str = "row"):
+        """Leave-one-out: row i = predict(construct(y, X, [source_i]), y[[source_i], :])."""
+        i_end = self.ns if i_end is None else i_end
+        return self._run("ss_predict_loo", (i_begin, i_end), i_end - i_begin, clean, out, layout)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            L.load().ss_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceSpMat:
+    """The sparse operand W of F = W*R on the device (CSR; cut into LDS-tile form on first wide use)."""
+
+    def __init__(self, W, dtype=np.float32):
+        import scipy.sparse as sp
+        lib = L.lib()
+        W = sp.csr_matrix(W)
+        self.shape = W.shape
+        self.dtype = np.dtype(dtype)
+        self._suf = _suffix(dtype)
+        p, i, v = _csr_parts(W, dtype)
+        self.nnz = int(len(i))
+        self._h = C.c_void_p()
+        fn = getattr(lib, f"ss_spmat_create_csr_{self._suf}")
+        L.check(fn(W.shape[0], W.shape[1], _ptr(p), _ptr(i), _ptr(v), 0, L.SS_MEM_HOST, C.byref(self._h)))
+
+    def cost(self, B: int):
+        b, f = C.c_double(), C.c_double()
+        L.check(L.load().ss_spmat_cost(self._h, B, C.byref(b), C.byref(f)))
+        return b.value, f.value
+
+    def spmm(self, R, out=None, colmajor: bool = False):
+        """F = W @ R.  R: (K, B).  colmajor=False: R, F are C-order (K,B)/(M,B) arrays.
+        colmajor=True: R is given as its transpose, a C-order (B, K) array, and F comes back as (B, M)."""
+        lib = L.lib()
+        M, K = self.shape
+        torch_in = _is_torch(R)
+        if not torch_in:
+            R = np.ascontiguousarray(R, dtype=self.dtype)
+        elif not R.is_contiguous():
+            R = R.contiguous()
+        if R.ndim == 1:
+            R = R.reshape(-1, 1) if not colmajor else R.reshape(1, -1)
+        if colmajor:
+            B, k_in = R.shape
+        else:
+            k_in, B = R.shape
+        if k_in != K:
+            raise ValueError(f"R has {k_in} rows, W has {K} columns")
+        shape = (B, M) if colmajor else (M, B)
+        if out is None:
+            if torch_in:
+                import torch
+                out = torch.empty(shape, dtype=R.dtype, device=R.device)
+            else:
+                out = np.empty(shape, dtype=self.dtype)
+        lay = L.SS_LAYOUT_COLMAJOR if colmajor else L.SS_LAYOUT_ROWMAJOR
+        if torch_in:
+            rp, fp, mem = R.data_ptr(), out.data_ptr(), L.SS_MEM_DEVICE
+        else:
+            rp, fp, mem = R.ctypes.data, out.ctypes.data, L.SS_MEM_HOST
+        fn = getattr(lib, f"ss_spmm_{self._suf}")
+        L.check(fn(self._h, rp, B, R.shape[1], lay, fp, shape[1], lay, mem))
+        return out
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            L.load().ss_spmat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

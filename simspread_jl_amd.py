@@ -1,0 +1,14 @@
+"""Import shim: the package directory is named ``simspread.jl_amd`` (with a dot), which the
+import system cannot address by name.  ``import simspread_jl_amd`` loads that directory as
+a regular package under this module's name."""
+import importlib.util
+import os
+import sys
+
+_here = os.path.dirname(os.path.abspath(__file__))
+_pkg_dir = os.path.join(_here, "simspread.jl_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_pkg_dir, "__init__.py"), submodule_search_locations=[_pkg_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

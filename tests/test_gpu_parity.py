@@ -1,0 +1,374 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Tolerances: fp64 results must
+agree to 1e-12 relative; fp32 results to 1e-5 relative to the largest score of the block (north_star:
+1e-5 relative fp64 tolerance), exact zeros must stay exact zeros."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import simspread_jl_amd as ss
+from oracle import simspread_oracle as O
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: 1e-5, np.float64: 1e-12}
+
+
+def assert_close(got, want, dtype):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    scale = max(np.abs(want).max(), 1e-300)
+    err = np.abs(got - want).max() / scale
+    assert err <= TOL[dtype], f"max err {err:.3e} (relative to the largest score)"
+    assert ((want == 0) <= (got == 0)).all(), "a structurally zero score became non-zero"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    ss.init(0)
+
+
+# ----------------------------------------------------------------------------- reference KATs through the mirror
+def test_kats_through_the_host_mirror(kats):
+    M = np.array(kats["k"]["M"], float)
+    assert int(ss.k(1, M)) == 0 and int(ss.k(M[0])) == 0
+    assert ss.k(M).ravel().tolist() == kats["k"]["row_degrees"]
+    c = kats["cutoff"]
+    y, z = np.array(c["y"]).reshape(-1, 1), np.array(c["z"])
+    for case in c["cases"]:
+        a = case["alpha"]
+        assert ss.cutoff(c["x"], a, False) == pytest.approx(case["x_bin"])
+        assert ss.cutoff(c["x"], a, True) == pytest.approx(case["x_w"])
+        np.testing.assert_array_equal(ss.cutoff(y, a, False).ravel(), case["y_bin"])
+        np.testing.assert_array_equal(ss.cutoff(y, a, True).ravel(), case["y_w"])
+        np.testing.assert_array_equal(ss.cutoff(z, a, False), case["z_bin"])
+        np.testing.assert_array_equal(ss.cutoff(z, a, True), case["z_w"])
+    f = kats["featurize"]
+    M0 = ss.NamedMatrix(f["M0"], f["rows"], f["cols"])
+    assert ss.featurize(M0, f["alpha"], False) == ss.NamedMatrix(f["unweighted"], f["rows"], f["out_cols"])
+    assert ss.featurize(M0, f["alpha"], True) == ss.NamedMatrix(f["weighted"], f["rows"], f["out_cols"])
+    assert ss.featurize(M0, f["alpha"]).names(2) == f["out_cols"]
+    s = kats["spread"]
+    got = ss.spread(np.array(s["M"], float))
+    assert np.linalg.norm(got - np.array(s["W"])) <= s["rtol"] * np.linalg.norm(got)
+
+
+def test_construct_kat(kats):
+    c = kats["construct"]
+    X = ss.NamedMatrix(c["X"], c["X_rows"], c["X_cols"])
+    y = ss.NamedMatrix(c["y"], c["y_rows"], c["y_cols"])
+    A, B = ss.construct(y, X, c["queries"])
+    assert A.names(1) == A.names(2) == c["node_order"]
+    assert B.names(1) == B.names(2) == c["node_order"]
+    X2 = ss.NamedMatrix(c["X"], c["X_rows"], c["X_rows"])
+    with pytest.raises(AssertionError, match=c["same_names_message"]):
+        ss.construct(y, X2, c["queries"])
+    X3 = ss.NamedMatrix(c["row_mismatch_X"], c["row_mismatch_rows"], c["X_cols"])
+    with pytest.raises(AssertionError, match=c["row_mismatch_message"]):
+        ss.construct(y, X3, c["queries"])
+    # dense view equals the oracle's literal block matrices
+    Ao, Bo = O.construct_queries(O.Named(c["y"], c["y_rows"], c["y_cols"]), O.Named(c["X"], c["X_rows"], c["X_cols"]),
+                                 c["queries"])
+    np.testing.assert_array_equal(A.array, Ao.array)
+    np.testing.assert_array_equal(B.array, Bo.array)
+
+
+def test_predict_kat_exact_both_call_forms(kats):
+    p = kats["predict"]
+    A = ss.NamedMatrix(p["A"], p["names"], p["names"])
+    B = ss.NamedMatrix(p["B"], p["names"], p["names"])
+    y = ss.NamedMatrix(p["y"], p["y_rows"], p["y_cols"])
+    want = ss.NamedMatrix(p["yhat"], p["y_rows"], p["y_cols"])
+    assert ss.predict(A, B, y) == want           # exact ==, like test/runtests.jl:156
+    assert ss.predict((A, B), y) == want
+    assert ss.predict(A, B, y, GPU=True) == want  # fp32 path: values are exactly representable
+
+
+def test_clean_kat(kats):
+    c = kats["clean"]
+    A = ss.NamedMatrix(c["A"], c["names"], c["names"])
+    y = ss.NamedMatrix(c["y"], c["y_rows"], c["y_cols"])
+    yhat = ss.NamedMatrix(c["yhat_in"], c["y_rows"], c["y_cols"])
+    ss.clean(yhat, A, y)
+    assert yhat == ss.NamedMatrix(c["yhat_out"], c["y_rows"], c["y_cols"])
+
+
+# ----------------------------------------------------------------------------- tutorial-shaped chain vs the literal oracle
+@pytest.mark.parametrize("weighted", [False, True])
+def test_featurize_construct_predict_chain_vs_literal(weighted):
+    rng = np.random.default_rng(11)
+    n, nt, ntest = 40, 9, 7
+    S = rng.random((n, n)); S = (S + S.T) / 2; np.fill_diagonal(S, 1.0)
+    nm = [f"D{i:03d}" for i in range(n)]
+    train, test = nm[:-ntest], nm[-ntest:]
+    Y = (rng.random((n, nt)) < 0.3).astype(float)
+    tn = [f"T{i}" for i in range(nt)]
+    # host mirror
+    DD, yy = ss.NamedMatrix(S, nm, nm), ss.NamedMatrix(Y, nm, tn)
+    Xtr = ss.featurize(DD.sub(train, train), 0.55, weighted)
+    Xte = ss.featurize(DD.sub(test, train), 0.55, weighted)
+    G = ss.construct(yy.sub(train, tn), yy.sub(test, tn), Xtr, Xte)
+    got_te = ss.predict(G, yy.sub(test, tn))
+    got_tr = ss.predict(G, yy.sub(train, tn))
+    # literal oracle
+    oD, oy = O.Named(S, nm, nm), O.Named(Y, nm, tn)
+    oXtr = O.featurize(oD.sub(train, train), 0.55, weighted)
+    oXte = O.featurize(oD.sub(test, train), 0.55, weighted)
+    A, B = O.construct_split(oy.sub(train, tn), oy.sub(test, tn), oXtr, oXte)
+    assert_close(got_te.array, O.predict(A, B, oy.sub(test, tn)).array, np.float64)
+    assert_close(got_tr.array, O.predict(A, B, oy.sub(train, tn)).array, np.float64)
+    assert got_te.names(1) == test and got_te.names(2) == tn
+    # 3-layer graph, predict(A, ytrain)
+    A3 = ss.construct(yy.sub(train, tn), Xtr)
+    got3 = ss.predict(A3, yy.sub(train, tn))
+    assert_close(got3.array, O.predict_single(O.construct_single(oy.sub(train, tn), oXtr), oy.sub(train, tn)).array,
+                 np.float64)
+    # mixed query + source rows in one call, permuted columns
+    rows = [test[2], train[5], test[0]]
+    cols = tn[::-1]
+    got_mix = ss.predict(G, yy.sub(rows, cols))
+    assert_close(got_mix.array, O.predict(A, B, oy.sub(rows, cols)).array, np.float64)
+
+
+# ----------------------------------------------------------------------------- engine parity on seeded synthetic graphs
+CASES = [
+    # nq, ns, nf, nt, dx, dy, weighted
+    (33, 70, 70, 41, 0.15, 0.10, True),
+    (128, 257, 200, 130, 0.08, 0.04, False),
+    (5, 64, 64, 1, 0.3, 0.5, True),
+    (1, 3, 3, 2, 0.9, 0.9, False),
+    (200, 1000, 1000, 777, 0.05, 0.01, True),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("case", CASES)
+def test_predict_query_and_source_rows(case, dtype):
+    nq, ns, nf, nt, dx, dy, weighted = case
+    Xq, Xs, Ys = O.synth_bipartite(nq, ns, nf, nt, dx, dy, seed=100 + nq, weighted=weighted, dtype=dtype)
+    # make a zero-degree feature, an isolated source and an empty target when the graph is big enough
+    if ns > 10:
+        Xs = Xs.tolil(); Ys = Ys.tolil()
+        Xs[:, 1] = 0; Xs[2, :] = 0; Ys[2, :] = 0; Ys[:, nt - 1] = 0
+        Xs = Xs.tocsr(); Ys = Ys.tocsr()
+    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=dtype)
+    f64 = [m.astype(np.float64) for m in (Xq, Xs, Ys)]
+    assert_close(g.predict("query"), O.predict_factored(*f64, rows="query"), dtype)
+    assert_close(g.predict("source"), O.predict_factored(*f64, rows="source"), dtype)
+    kf, ks, kt = g.degrees()
+    okf, oks, okt = O.degrees(f64[1], f64[2])
+    np.testing.assert_array_equal(kf, okf); np.testing.assert_array_equal(ks, oks); np.testing.assert_array_equal(kt, okt)
+    # sub-range + fused clean! + column-major (Julia) layout
+    lo, hi = nq // 3, nq
+    want = O.predict_factored(*f64, rows="query")[lo:hi].copy()
+    want[:, okt == 0] = -99.0
+    got = g.predict("query", lo, hi, clean=True, layout="col")
+    assert got.flags.f_contiguous or got.shape[0] == 1 or got.shape[1] == 1
+    assert_close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dense_assembly_with_fused_cutoff_matches_featurize(dtype):
+    rng = np.random.default_rng(5)
+    nq, ns, nt = 37, 150, 60
+    Sq, Ss = rng.random((nq, ns)).astype(dtype), rng.random((ns, ns)).astype(dtype)
+    Y = (rng.random((ns, nt)) < 0.05).astype(dtype)
+    Ss[4, 9] = 0.7; Sq[0, 0] = 0.7   # exactly alpha: `>=` keeps it
+    for weighted in (False, True):
+        g = ss.DeviceGraph.from_dense(Sq, Ss, Y, alpha=dtype(0.7), weighted=weighted, dtype=dtype)
+        Xq = O.cutoff(Sq.astype(np.float64), float(dtype(0.7)), weighted)
+        Xs = O.cutoff(Ss.astype(np.float64), float(dtype(0.7)), weighted)
+        assert g.nnz_xq == np.count_nonzero(Xq) and g.nnz_xs == np.count_nonzero(Xs)
+        assert_close(g.predict("query"), O.predict_factored(Xq, Xs, Y.astype(np.float64)), dtype)
+
+
+def test_multi_chunk_and_row_batches(monkeypatch):
+    # force several LDS chunks of W's columns and several transfer batches; results must not change
+    Xq, Xs, Ys = O.synth_bipartite(150, 700, 700, 300, 0.05, 0.03, seed=9, dtype=np.float32)
+    want = O.predict_factored(*(m.astype(np.float64) for m in (Xq, Xs, Ys)))
+    monkeypatch.setenv("SS_SELL_CHUNK", "128")
+    monkeypatch.setenv("SS_TRANSFER_BYTES", str(1 << 20))
+    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    got = g.predict("query", clean=True)
+    kt = O.degrees(Xs, Ys)[2]
+    want[:, kt == 0] = -99.0
+    assert_close(got, want, np.float32)
+
+
+def test_wide_source_row_needs_chunked_transfer():
+    # ns larger than one LDS accumulator of the transfer kernel (16384 floats)
+    ns, nq, nt = 40000, 16, 50
+    Xq, Xs, Ys = O.synth_bipartite(nq, ns, 300, nt, 0.02, 0.001, seed=21, dtype=np.float32)
+    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    assert_close(g.predict("query"), O.predict_factored(*(m.astype(np.float64) for m in (Xq, Xs, Ys))), np.float32)
+
+
+def test_explicit_zeros_are_not_edges():
+    Xq, Xs, Ys = O.synth_bipartite(10, 40, 40, 12, 0.2, 0.2, seed=2, dtype=np.float64)
+    Xs2 = Xs.copy(); Xs2.data[::3] = 0.0     # stored zeros: not neighbours, not counted in degrees
+    g = ss.DeviceGraph.from_sparse(Xq, Xs2, Ys, dtype=np.float64)
+    Xs3 = Xs2.copy(); Xs3.eliminate_zeros()
+    assert g.nnz_xs == Xs3.nnz
+    assert_close(g.predict("query"), O.predict_factored(Xq, Xs3, Ys), np.float64)
+
+
+def test_empty_and_degenerate_inputs():
+    e = sp.csr_matrix((0, 5)); Xs = sp.csr_matrix((4, 5)); Ys = sp.csr_matrix((4, 3))
+    g = ss.DeviceGraph.from_sparse(e, Xs, Ys, dtype=np.float32)
+    assert g.predict("query").shape == (0, 3)
+    np.testing.assert_array_equal(g.predict("source"), np.zeros((4, 3), np.float32))
+    np.testing.assert_array_equal(g.predict("source", clean=True), np.full((4, 3), -99, np.float32))
+
+
+def test_bad_inputs_are_rejected_not_faulted():
+    from simspread_jl_amd import _lib as L
+    import ctypes as C
+    lib = L.lib()
+    ptr = np.array([0, 2, 3], np.int64); idx = np.array([3, 1, 0], np.int32); val = np.ones(3, np.float32)
+    h = C.c_void_p()
+    z = np.zeros(1, np.int64)
+    def mk(p, i, cols):
+        return lib.ss_spmat_create_csr_f32(2, cols, p.ctypes.data, i.ctypes.data, val.ctypes.data, 0, 0, C.byref(h))
+    assert mk(ptr, idx, 4) == -1 and "increasing" in lib.ss_last_error().decode()
+    assert mk(ptr, np.array([0, 9, 1], np.int32), 4) == -1 and "range" in lib.ss_last_error().decode()
+    assert mk(np.array([0, 5, 3], np.int64), idx, 4) == -1
+    g = ss.DeviceGraph.from_sparse(sp.csr_matrix((2, 3)), sp.csr_matrix((3, 3)), sp.csr_matrix((3, 2)))
+    with pytest.raises(ss.SimSpreadError, match="row range"):
+        g.predict("query", 0, 5)
+    with pytest.raises(ss.SimSpreadError, match="leave-one-out"):
+        g.predict_loo()
+    g64 = ss.DeviceGraph.from_sparse(None, sp.identity(3, format="csr"), sp.csr_matrix((3, 2)), dtype=np.float64)
+    out = np.zeros((3, 2), np.float32)
+    assert lib.ss_predict_f32(g64._h, 1, 0, 3, 0, out.ctypes.data, 2, 0, 0) == -1  # precision mismatch
+
+
+# ----------------------------------------------------------------------------- leave-one-out
+def _iris():
+    here = os.path.join(os.path.dirname(__file__), "golden", "iris")
+    def read(p):
+        with open(os.path.join(here, p)) as f:
+            lines = f.read().splitlines()
+        return [l.split()[0] for l in lines[1:]], lines[0].split(), np.array([[float(v) for v in l.split()[1:]] for l in lines[1:]])
+    rows, _, F = read("iris.features")
+    _, cc, Cm = read("iris.classes")
+    S = np.minimum(F[:, None, :], F[None, :, :]).sum(-1) / np.maximum(F[:, None, :], F[None, :, :]).sum(-1)
+    return rows, cc, S, Cm
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_iris_full_loo_vs_per_fold_reference_semantics(dtype, weighted):
+    rows, cc, S, Cm = _iris()
+    g = ss.DeviceGraph.from_dense(None, S.astype(dtype), Cm.astype(dtype), alpha=dtype(0.9), weighted=weighted, dtype=dtype)
+    got = g.predict_loo(clean=True)
+    X = O.cutoff(S.astype(dtype).astype(np.float64), float(dtype(0.9)), weighted)
+    want = O.predict_loo_factored(X, Cm, clean_flag=True)
+    assert_close(got, want, dtype)
+    # three folds the long way round: literal construct(y, X, [q]) + predict + clean!
+    Xn, Yn = O.Named(X, rows, ["f" + r for r in rows]), O.Named(Cm, rows, cc)
+    for i in (0, 77, 149):
+        A, B = O.construct_queries(Yn, Xn, [rows[i]])
+        yq = Yn.sub([rows[i]], cc)
+        yh = O.predict(A, B, yq); O.clean(yh, A, yq)
+        assert_close(got[i:i + 1], yh.array, dtype)
+
+
+def test_loo_clean_flags_targets_whose_only_edge_is_the_query():
+    rng = np.random.default_rng(3)
+    n, nt = 90, 20
+    S = rng.random((n, n)); S = (S + S.T) / 2; np.fill_diagonal(S, 1.0)
+    Y = (rng.random((n, nt)) < 0.1).astype(np.float64)
+    Y[:, 4] = 0; Y[17, 4] = 1      # single edge
+    Y[:, 5] = 0                    # no edge at all
+    X = O.cutoff(S, 0.6, True)
+    g = ss.DeviceGraph.from_dense(None, S, Y, alpha=0.6, weighted=True, dtype=np.float64)
+    got = g.predict_loo(10, 60, clean=True)
+    want = O.predict_loo_factored(X, Y, clean_flag=True, queries=range(10, 60))
+    assert_close(got, want, np.float64)
+    assert got[7, 4] == -99 and (got[:, 5] == -99).all() and (got[np.arange(50) != 7, 4] != -99).all()
+
+
+def test_loo_through_the_mirror_equals_fold_loop():
+    rng = np.random.default_rng(8)
+    n, nt = 30, 5
+    S = rng.random((n, n)); S = (S + S.T) / 2; np.fill_diagonal(S, 1.0)
+    nm = [f"d{i:02d}" for i in range(n)]; tn = [f"t{i}" for i in range(nt)]
+    y = ss.NamedMatrix((rng.random((n, nt)) < 0.3).astype(float), nm, tn)
+    X = ss.featurize(ss.NamedMatrix(S, nm, nm), 0.5, True)
+    g = ss.DeviceGraph.from_dense(None, X.array, y.array, dtype=np.float64)
+    fast = g.predict_loo(clean=True)
+    for i in (0, 13, 29):
+        A, B = ss.construct(y, X, [nm[i]])
+        yq = y.sub([nm[i]], tn)
+        yh = ss.predict((A, B), yq)
+        ss.clean(yh, A, yq)
+        assert_close(fast[i:i + 1], yh.array, np.float64)
+
+
+# ----------------------------------------------------------------------------- raw W*R SpMM
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 7, 16, 33, 64, 65, 200])
+def test_spmm_against_scipy(B, dtype):
+    rng = np.random.default_rng(B)
+    M, K = 517, 389
+    W = sp.random(M, K, density=0.06, format="csr", random_state=rng, dtype=np.float64)
+    W.data = rng.random(W.nnz) + 0.5
+    if B % 2 == 0:
+        W.data[:] = 1.0  # pattern-only operand (binary Y)
+    R = rng.standard_normal((K, B))
+    w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
+    want = W @ R
+    assert_close_signed(w.spmm(R.astype(dtype)), want, dtype)                       # row-major operands
+    assert_close_signed(w.spmm(np.ascontiguousarray(R.T).astype(dtype), colmajor=True).T, want, dtype)
+    by, fl = w.cost(B)
+    vb = np.dtype(dtype).itemsize
+    assert by == W.nnz * (vb + 4) + (M + 1) * 4 + K * B * vb + M * B * vb and fl == 2.0 * W.nnz * B
+
+
+def assert_close_signed(got, want, dtype):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    # signed operands: bound the error by the sum of magnitudes, not by the (possibly cancelling) result
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+    assert err <= (2e-5 if dtype == np.float32 else 1e-12), err
+
+
+def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
+    rng = np.random.default_rng(0)
+    M, K = 300, 5000
+    rows = []
+    for m in range(M):
+        n = 0 if m % 7 == 0 else (K if m == 11 else int(rng.integers(1, 40)))
+        cols = np.sort(rng.choice(K, n, replace=False))
+        rows.append(cols)
+    indptr = np.cumsum([0] + [len(r) for r in rows])
+    W = sp.csr_matrix((rng.random(indptr[-1]) + 0.1, np.concatenate(rows), indptr), shape=(M, K))
+    R = rng.random((K, 70))
+    monkeypatch.setenv("SS_SELL_CHUNK", "1000")
+    w = ss.DeviceSpMat(W, dtype=np.float64)
+    assert_close(w.spmm(R), W @ R, np.float64)
+    assert_close(w.spmm(R[:, :5].copy()), W @ R[:, :5], np.float64)
+
+
+# ----------------------------------------------------------------------------- BASELINE config 2 at full size
+def test_config2_full_size_sampled_rows_and_linearity():
+    nq = ns = nf = nt = 10_000
+    Xq, Xs, Ys = O.synth_bipartite(nq, ns, nf, nt, 0.05, 0.01, seed=20250222 + 2, weighted=True, dtype=np.float32)
+    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    got = g.predict("query")
+    assert got.shape == (nq, nt) and np.isfinite(got).all()
+    rows = [0, 1, 4999, 5000, 9998, 9999]
+    f64 = [m.astype(np.float64) for m in (Xq, Xs, Ys)]
+    for r in rows:
+        want = c_oracle.predict_query(*f64, r0=r, r1=r + 1)
+        assert_close(got[r:r + 1], want, np.float32)
+    # size-independent properties: scores are linear in the query's feature weights ...
+    Xq2 = Xq.copy(); Xq2.data *= np.float32(0.5)
+    g2 = ss.DeviceGraph.from_sparse(Xq2[:512], Xs, Ys, dtype=np.float32)
+    np.testing.assert_allclose(g2.predict("query"), 0.5 * got[:512], rtol=2e-6, atol=0)
+    # ... and resource is conserved: every query's scores sum to sum_s T[q,s] * (#targets of s)
+    T = O.transfer_factored(f64[0][:64], f64[1], f64[2])
+    np.testing.assert_allclose(got[:64].astype(np.float64).sum(1), T @ np.asarray((f64[2] != 0).sum(1)).ravel(), rtol=1e-5)
