@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the SimSpread hot path on MI355X.
+
+One "step" = one full predict() pass (stage 1 transfer block + stage 2 W*R SpMM) over one batch of
+synthetic input that is already resident in HBM: BASELINE.json configs[1]
+    10k queries x 10k targets, 10k sources/features, 5 % similarity, 1 % bipartite density, fp32.
+Multi-GPU (torch.distributed, one rank per GPU): query rows are independent, so every rank scores its
+own 10k-query shard against the replicated source/target graph (weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0 (driver contract) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3    # fp32 vector == fp32-input MFMA peak
+
+
+def synth_c2(nq, ns, nf, nt, dx, dy, seed, rank):
+    """Seeded C2-shaped inputs.  The graph (Xs, Ys) is the same on every rank, the
+    query block differs per rank."""
+    import scipy.sparse as sp
+    rng_g = np.random.default_rng(seed)
+    rng_q = np.random.default_rng(seed + 1000 + rank)
+
+    def rand_csr(rng, r, c, d, weighted):
+        m = sp.random(r, c, density=d, format="csr", random_state=rng, dtype=np.float32)
+        m.data = (0.5 + 0.5 * (1.0 - rng.random(m.nnz))).astype(np.float32) if weighted else np.ones(m.nnz, np.float32)
+        m.sort_indices()
+        return m
+
+    Xs = rand_csr(rng_g, ns, nf, dx, True).tolil()
+    Xs.setdiag(1.0)
+    Xs = Xs.tocsr().astype(np.float32)
+    Xs.sort_indices()
+    Ys = rand_csr(rng_g, ns, nt, dy, False)
+    Xq = rand_csr(rng_q, nq, nf, dx, True)
+    return Xq, Xs, Ys
+
+
+def csr_bytes(nnz, rows, vb=4):
+    return nnz * (vb + 4) + (rows + 1) * 4
+
+
+def spmm_sweep(ss, torch, steps=5):
+    """Narrow-R regime of the W*R SpMM at the north-star size: W 100k x 100k, 1 % (nnz ~1e8), fp32,
+    B in {1,4,16,64}; HBM roofline fraction on algorithmic bytes."""
+    import ctypes as C
+    from simspread_jl_amd import _lib as L
+    M = K = 100_000
+    dens = 0.01
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(20250222 + 3)
+    n_draw = int(M * K * dens)
+    rows = torch.randint(0, M, (n_draw,), device=dev, generator=g, dtype=torch.int64)
+    cols = torch.randint(0, K, (n_draw,), device=dev, generator=g, dtype=torch.int64)
+    keys = torch.unique(rows * K + cols)  # sorted, duplicates removed
+    del rows, cols
+    r = torch.div(keys, K, rounding_mode="floor")
+    idx = (keys - r * K).to(torch.int32)
+    ptr = torch.zeros(M + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(r, minlength=M), 0)
+    nnz = int(keys.numel())
+    del keys, r
+    val = torch.rand(nnz, device=dev, dtype=torch.float32, generator=g) + 0.5
+    lib = L.lib()
+    h = C.c_void_p()
+    L.check(lib.ss_spmat_create_csr_f32(M, K, ptr.data_ptr(), idx.data_ptr(), val.data_ptr(), 0, L.SS_MEM_DEVICE, C.byref(h)))
+    out = []
+    for B in (1, 4, 16, 64):
+        R = torch.rand(K, B, device=dev, dtype=torch.float32, generator=g)
+        F = torch.empty(M, B, device=dev, dtype=torch.float32)
+        ms = []
+        for it in range(steps + 2):
+            L.check(lib.ss_spmm_f32(h, R.data_ptr(), B, B, 0, F.data_ptr(), B, 0, L.SS_MEM_DEVICE))
+            if it >= 2:
+                ms.append(ss.timing_last()["spmm_ms"])
+        t = float(np.mean(ms)) * 1e-3
+        by = csr_bytes(nnz, M) + K * B * 4 + M * B * 4
+        out.append({"B": B, "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
+                    "frac_hbm": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "bytes": by})
+    lib.ss_spmat_destroy(h)
+    return {"workload": "W 100k x 100k, 1% (nnz %d), fp32, CSR streamed once" % nnz, "results": out}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--n", type=int, default=10_000, help="sources = features = targets")
+    ap.add_argument("--dx", type=float, default=0.05)
+    ap.add_argument("--dy", type=float, default=0.01)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the score blocks (outside `value`)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+
+    import simspread_jl_amd as ss
+    ss.init(local_rank)
+
+    nq, n = args.nq, args.n
+    Xq, Xs, Ys = synth_c2(nq, n, n, n, args.dx, args.dy, seed=20250222 + 2, rank=rank)
+    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    scores = torch.empty((nq, n), dtype=torch.float32, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        g.predict("query", out=scores)
+    barrier()
+    t0 = time.perf_counter()
+    stage = {"transfer_ms": [], "spmm_ms": [], "total_ms": []}
+    for _ in range(args.steps):
+        g.predict("query", out=scores)
+        t = ss.timing_last()
+        for k_ in stage:
+            stage[k_].append(t[k_])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    edges_per_step = nq * n * world
+    value = edges_per_step / (elapsed / args.steps)
+
+    gather_ms = None
+    if args.gather and world > 1:
+        bufs = [torch.empty_like(scores) for _ in range(world)]
+        barrier()
+        tg = time.perf_counter()
+        dist.all_gather(bufs, scores)
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+
+    if rank == 0:
+        nnz_w = g.nnz_ys
+        spmm_ms = float(np.mean(stage["spmm_ms"]))
+        transfer_ms = float(np.mean(stage["transfer_ms"]))
+        # dominant kernel: the W*R SpMM (stage 2).  Algorithmic work per launch:
+        #   bytes = CSR(W) + K*B*4 + M*B*4,  flops = 2*nnz(W)*B,  B = nq columns of R per launch
+        spmm_bytes = csr_bytes(nnz_w, n) + n * nq * 4 + n * nq * 4
+        spmm_flops = 2.0 * nnz_w * nq
+        achieved_tf = spmm_flops / (spmm_ms * 1e-3) / 1e12
+        roofline = {
+            "kernel": "spmm_sell_kernel<float,4> (stage 2, F = W*R, B = %d)" % nq,
+            "bound": "mfma",
+            "bound_note": "wide-R SpMM is FMA/LDS-gather bound; peak = fp32 vector rate = fp32-input MFMA rate (157.3 TF)",
+            "achieved": round(achieved_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "avg_launch_ms": round(spmm_ms, 4),
+            "algorithmic_bytes": spmm_bytes,
+            "algorithmic_GBps": round(spmm_bytes / (spmm_ms * 1e-3) / 1e9, 1),
+            "frac_hbm": round(spmm_bytes / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "stage1_transfer_ms": round(transfer_ms, 4),
+            "predict_algorithmic_bytes": csr_bytes(g.nnz_xq, nq) + csr_bytes(g.nnz_xs, n) + csr_bytes(nnz_w, n) + nq * n * 4,
+        }
+        result = {
+            "metric": "predicted edges/sec + achieved HBM GB/s, W*R SpMM",
+            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d queries x %d targets per GPU, %d sources/features, "
+                                   "%.0f%% similarity, %.0f%% bipartite density, fp32, full predict()"
+                                   % (nq, n, n, args.dx * 100, args.dy * 100),
+                       "queries_per_gpu": nq, "sources": n, "features": n, "targets": n,
+                       "nnz_Xq": g.nnz_xq, "nnz_Xs": g.nnz_xs, "nnz_Ys": g.nnz_ys, "sharding": "query rows, no collective"},
+            "roofline": roofline,
+        }
+        if gather_ms is not None:
+            result["score_gather_ms"] = gather_ms
+        if not args.no_sweep and world == 1:
+            try:
+                result["spmm_narrow_sweep"] = spmm_sweep(ss, torch)
+            except Exception as e:  # the sweep is auxiliary; never lose the headline line
+                result["spmm_narrow_sweep"] = {"error": repr(e)}
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import c_oracle
+            nsample = 128
+            f64 = [m.astype(np.float64) for m in (Xq, Xs, Ys)]
+            c_oracle.predict_query(*f64, r0=0, r1=8)  # warm
+            tc = time.perf_counter()
+            ref = c_oracle.predict_query(*f64, r0=0, r1=nsample)
+            dt = time.perf_counter() - tc
+            # keep the sample around 10-30 s of CPU work
+            if dt < 5.0:
+                nsample = min(nq, int(nsample * 12.0 / max(dt, 1e-3)))
+                tc = time.perf_counter()
+                ref = c_oracle.predict_query(*f64, r0=0, r1=nsample)
+                dt = time.perf_counter() - tc
+            got = scores[:nsample].cpu().numpy()
+            err = float(np.abs(got - ref).max() / np.abs(ref).max())
+            result["cpu_baseline"] = {
+                "value": nsample * n / dt, "unit": "edges/s", "cores": c_oracle.max_threads(), "kind": "port",
+                "sample": "first %d of %d query rows of the same workload, fp64 CSR C/OpenMP restatement "
+                          "(oracle/factored.c), %.1f s" % (nsample, nq, dt),
+                "max_rel_err_gpu_vs_cpu": err,
+            }
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -272,6 +272,31 @@ static int graph_sell(Graph<T>& g) {
   return SS_OK;
 }
 
+// stage-1 operands: X' (and Y' for source rows) cut into column chunks.  The chunk is sized so that an
+// average sub-row fills one 64-lane load (SC ~ 64 * ns / mean row length), the chunk count is a multiple
+// of 8 so that chunk c always meets the same XCD's L2.
+template <class T>
+static int graph_chunked(Graph<T>& g, bool need_y) {
+  if (g.XsTc.SC == 0) {
+    const int64_t ns = g.ns > 0 ? g.ns : 1;
+    const double mean_len = g.XsT.rows > 0 ? (double)g.XsT.nnz / (double)g.XsT.rows : 0.0;
+    int64_t sc = mean_len > 1.0 ? (int64_t)(64.0 * (double)ns / mean_len) : ns;
+    const int64_t sc_max = sizeof(T) == 4 ? 8192 : 4096;
+    if (sc > sc_max) sc = sc_max;
+    if (sc < 256) sc = 256;
+    if (const char* e = getenv("SS_TRANSFER_CHUNK")) {
+      const long long v = atoll(e);
+      if (v >= 16 && v <= 16384) sc = v;
+    }
+    int64_t nch = ceil_div(ns, sc);
+    if (nch > 1) nch = ceil_div(nch, 8) * 8;
+    sc = ceil_div(ceil_div(ns, nch), 4) * 4;
+    SS_TRY(chunked_build<T>(g.XsT, (int)sc, g.XsTc));
+  }
+  if (need_y && g.YsTc.SC == 0) SS_TRY(chunked_build<T>(g.YsT, g.XsTc.SC, g.YsTc));
+  return SS_OK;
+}
+
 // rows of T held at once (stage-1 output, stage-2 input)
 static int64_t transfer_batch_rows(int64_t nrows, int64_t nj, size_t elem) {
   int64_t cap_bytes = 2LL << 30;
@@ -292,6 +317,7 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
   const int64_t nrows = row_end - row_begin;
   const int64_t nj = g.ns;
   SS_TRY(graph_sell(g));
+  SS_TRY(graph_chunked(g, kind == SS_ROWS_SOURCE));
   const int64_t rb = transfer_batch_rows(nrows, nj, sizeof(T));
   // the transfer block lives in the handle so that repeated predictions do not re-allocate
   const size_t need = (size_t)rb * (size_t)(nj > 0 ? nj : 1);
@@ -302,16 +328,16 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
     {
       StageTimer t1(ST_TRANSFER);
       if (kind == 2) {
-        SS_TRY(launch_transfer_loo<T>(g.Xs, g.XsT, g.kf.p, g.ks.p, row_begin + r0, nb, Tbuf.p, nj));
+        SS_TRY(launch_transfer_loo<T>(g.Xs, g.XsTc, g.kf.p, g.ks.p, row_begin + r0, nb, Tbuf.p, nj));
       } else if (kind == SS_ROWS_QUERY) {
         const DevCsr<T>* L[2] = {&g.Xq, nullptr};
-        const DevCsr<T>* M[2] = {&g.XsT, nullptr};
+        const DevChunked<T>* M[2] = {&g.XsTc, nullptr};
         const T* inv1[2] = {g.inv_kf.p, nullptr};
         SS_TRY(launch_transfer<T>(1, L, inv1, M, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj));
       } else {
         // source rows: feature path + target path
         const DevCsr<T>* L[2] = {&g.Xs, &g.Ys};
-        const DevCsr<T>* M[2] = {&g.XsT, &g.YsT};
+        const DevChunked<T>* M[2] = {&g.XsTc, &g.YsTc};
         const T* inv1[2] = {g.inv_kf.p, g.inv_kt.p};
         SS_TRY(launch_transfer<T>(2, L, inv1, M, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj));
       }

@@ -494,6 +494,80 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   return SS_OK;
 }
 
+// ------------------------------------------------------------------ CSR -> column-chunked CSR (stage-1 operand)
+// one thread per (chunk, row): entries of the row inside the chunk
+__global__ void chunk_count_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, int64_t rows, int SC,
+                                   int nchunks, int* __restrict__ cnt) {
+  const int64_t total = rows * nchunks;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / rows);
+    const int64_t r = i - (int64_t)c * rows;
+    const int lo = ptr[r], hi = ptr[r + 1];
+    const int64_t k0 = (int64_t)c * SC, k1 = k0 + SC;
+    int a = lo, b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
+    const int first = a;
+    b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
+    cnt[i] = a - first;
+  }
+}
+
+// wave per (chunk, row): copy the sub-row with chunk-local indices
+template <class T>
+__global__ void chunk_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
+                                  int64_t rows, int SC, int nchunks, const int* __restrict__ off,
+                                  unsigned short* __restrict__ oidx, T* __restrict__ oval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t total = rows * nchunks;
+  for (int64_t i = wave0; i < total; i += nwaves) {
+    const int c = (int)(i / rows);
+    const int64_t r = i - (int64_t)c * rows;
+    const int o = off[i], n = off[i + 1] - o;
+    if (n == 0) continue;
+    const int lo = ptr[r], hi = ptr[r + 1];
+    const int64_t k0 = (int64_t)c * SC;
+    int a = lo, b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
+    for (int x = lane; x < n; x += 64) {
+      oidx[o + x] = (unsigned short)(idx[a + x] - k0);
+      oval[o + x] = val[a + x];
+    }
+  }
+}
+
+template <class T>
+int chunked_build(const DevCsr<T>& in, int SC, DevChunked<T>& out) {
+  hipStream_t st = ctx().stream;
+  if (SC < 1 || SC > 65536) return fail(SS_EINVAL, "transfer chunk size out of range");
+  out.rows = in.rows;
+  out.cols = in.cols;
+  out.nnz = in.nnz;
+  out.SC = SC;
+  out.nchunks = (int)(in.cols > 0 ? ceil_div(in.cols, SC) : 1);
+  const int64_t total = in.rows * out.nchunks;
+  SS_TRY(out.off.alloc(total + 1));
+  SS_TRY(out.idx.alloc(in.nnz));
+  SS_TRY(out.val.alloc(in.nnz));
+  if (total == 0) {
+    SS_HIP(hipMemsetAsync(out.off.p, 0, sizeof(int), st));
+    return SS_OK;
+  }
+  DevBuf<int> cnt;
+  SS_TRY(cnt.alloc(total));
+  hipLaunchKernelGGL(chunk_count_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p, in.rows, SC,
+                     out.nchunks, cnt.p);
+  SS_LAUNCH_CHECK();
+  SS_TRY(exclusive_scan_int(cnt.p, out.off.p, total));
+  hipLaunchKernelGGL(chunk_fill_kernel<T>, dim3(grid_for(total * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p,
+                     in.val.p, in.rows, SC, out.nchunks, out.off.p, out.idx.p, out.val.p);
+  SS_LAUNCH_CHECK();
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
 // ------------------------------------------------------------------ degrees + transposes of a graph
 template <class T>
 __global__ void degree_kernel(const int* __restrict__ pa, const int* __restrict__ pb, int64_t n, int* __restrict__ k,
@@ -568,6 +642,7 @@ int graph_finalize_general(Graph<T>& g) {
   template int csr_from_user<T>(int64_t, int64_t, const int64_t*, const int32_t*, const T*, int, int, DevCsr<T>&); \
   template int csr_from_dense<T>(const T*, int64_t, int64_t, int64_t, bool, T, bool, int, DevCsr<T>&);         \
   template int csr_transpose<T>(const DevCsr<T>&, DevCsr<T>&);                                                 \
+  template int chunked_build<T>(const DevCsr<T>&, int, DevChunked<T>&);                                        \
   template int sell_build<T>(const DevCsr<T>&, int, DevSell<T>&);                                              \
   template int graph_finalize<T>(Graph<T>&);                                                                   \
   template int graph_finalize_general<T>(Graph<T>&);

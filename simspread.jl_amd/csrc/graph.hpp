@@ -33,6 +33,19 @@ struct DevSell {
   DevBuf<T> val;                // [nquads][64][4] unless binary
 };
 
+// CSR cut into column chunks of SC columns, stored chunk-major with chunk-local 16-bit indices:
+// sub-row (c, r) = entries off[c*rows + r] .. off[c*rows + r + 1].  Stage 1 gives chunk c of every
+// transfer row to workgroups with blockIdx % nchunks == c, so one XCD's L2 only ever sees the
+// sub-rows of "its" chunks (nchunks is a multiple of 8).
+template <class T>
+struct DevChunked {
+  int64_t rows = 0, cols = 0, nnz = 0;
+  int SC = 0, nchunks = 0;
+  DevBuf<int> off;             // [nchunks*rows + 1]
+  DevBuf<unsigned short> idx;  // [nnz]
+  DevBuf<T> val;               // [nnz]
+};
+
 template <class T>
 struct Graph {
   int64_t nq = 0, ns = 0, nf = 0, nt = 0;
@@ -47,6 +60,7 @@ struct Graph {
   // stage-2 operand, built lazily per tile width
   DevSell<T> W;
   int W_qt = 0;
+  DevChunked<T> XsTc, YsTc;  // stage-1 operands (YsTc only for source rows), built lazily
   DevBuf<T> Tws;  // workspace: rows of the transfer block T between stage 1 and stage 2
 };
 
@@ -68,6 +82,8 @@ template <class T>
 int csr_transpose(const DevCsr<T>& in, DevCsr<T>& out);
 template <class T>
 int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out);
+template <class T>
+int chunked_build(const DevCsr<T>& in, int SC, DevChunked<T>& out);
 template <class T>
 int graph_finalize(Graph<T>& g);  // transposes + degrees
 template <class T>
@@ -91,12 +107,13 @@ template <class T>
 int launch_spread_dense(const T* G, int64_t rows, int64_t cols, int64_t ld, const int* deg, T* W, int64_t ldw);
 
 // stage 1: T[r][j] = inv2[j] * sum_terms sum_a L[r,a] * inv1[a] * Mt[a][j]   (rows row_begin..+nrows)
+// all Mt operands must share SC / nchunks
 template <class T>
-int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevCsr<T>* Mt[2],
+int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
                     const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld);
 // leave-one-out flavour: row i of X against X' with the rank-1 degree corrections
 template <class T>
-int launch_transfer_loo(const DevCsr<T>& X, const DevCsr<T>& XT, const int* kf, const int* ks,
+int launch_transfer_loo(const DevCsr<T>& X, const DevChunked<T>& XT, const int* kf, const int* ks,
                         int64_t i_begin, int64_t nrows, T* out, int64_t ld);
 
 // stage 2, wide: F[b][m] = sum_k W[m][k] * R[b][k]   (R, F "column-major": one row of length K / M per b)

@@ -11,8 +11,8 @@
 //   cutoff / row_degree / spread_dense   the element-wise pieces (src/core.jl:37-43,365-371,
 //                        src/graphs.jl:9-11)
 //
-// Wavefront = 64 lanes everywhere.  No float atomics touch global memory; stage 1 uses LDS
-// float atomics inside one workgroup only.
+// Wavefront = 64 lanes everywhere.  No float atomics anywhere: every sum has a fixed order, so
+// results are bitwise reproducible from run to run.
 #include "graph.hpp"
 
 namespace ss {
@@ -97,118 +97,137 @@ int launch_spread_dense(const T* G, int64_t rows, int64_t cols, int64_t ld, cons
 
 // ============================================================== stage 1: transfer rows
 template <class T>
+struct ChunkedView {
+  const int* off;            // [nchunks*rows + 1]
+  const unsigned short* idx; // chunk-local column
+  const T* val;
+  int64_t rows;
+};
+template <class T>
+static inline ChunkedView<T> view(const DevChunked<T>& m) {
+  return ChunkedView<T>{m.off.p, m.idx.p, m.val.p, m.rows};
+}
+
+template <class T>
 struct TransferArgs {
   int nterms;
   CsrView<T> L[2];
   const T* inv1[2];
-  CsrView<T> M[2];
+  ChunkedView<T> M[2];
   const T* inv2;
   const int* kf;  // LOO: integer degrees
   const int* ks;
   int64_t row_begin;
   int64_t nj;
-  int jc;  // columns of T held in LDS at a time
+  int SC;       // columns of T per workgroup (= chunk of the Mt operands)
+  int nchunks;
   T* out;
   int64_t ld;
 };
 
-__device__ __forceinline__ int lower_bound_dev(const int* __restrict__ a, int lo, int hi, int key) {
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (a[mid] < key) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
+// One single-wave workgroup per (row r of L, column chunk c of T); c = blockIdx % nchunks so that,
+// with the dispatcher dealing workgroups round-robin over the 8 XCDs, chunk c is always served by
+// the same XCD and the sub-rows of Mt it touches stay in that XCD's L2 (speed only -- any placement
+// is correct).  acc[j] (LDS, owned by this one wave) collects sum_a L[r,a]*inv1[a]*Mt[a][c*SC + j].
+// The wave takes U neighbours a of r at a time, issues all their global loads, then folds the
+// sub-rows in one after the other with plain LDS read-add-write: the columns inside one sub-row are
+// distinct and LDS operations of one wave execute in order, so no atomics are needed and the sum
+// order is fixed (bitwise reproducible).  Measured on MI355X: ds_add_f32 costs ~193 clk per
+// wave-instruction (lanes serialised), ds_add_f64 ~27, a plain read-add-write pair ~17
+// (tools/lds_atomic_bench.hip) -- which is why this is not an LDS-atomic kernel.
+constexpr int TRANSFER_THREADS = 64;
 
-// One workgroup per row r of L.  acc[j] (LDS) collects sum_a L[r,a]*inv1[a]*Mt[a][j]; every wave
-// takes every nwaves-th neighbour a of r and streams row a of Mt with coalesced loads.
-template <class T, bool LOO>
-__global__ void __launch_bounds__(256) transfer_kernel(TransferArgs<T> p) {
+template <class T, bool LOO, int U>
+__global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs<T> p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* acc = reinterpret_cast<T*>(smem_raw);
-  unsigned* bits = reinterpret_cast<unsigned*>(acc + p.jc);  // LOO only: j has the dropped feature
+  unsigned* bits = reinterpret_cast<unsigned*>(acc + p.SC);  // LOO only: source owns the dropped feature
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int64_t r = blockIdx.x;
+  const int c = blockIdx.x % p.nchunks;
+  const int64_t r = blockIdx.x / p.nchunks;
   const int64_t gr = p.row_begin + r;
-  const bool chunked = p.nj > p.jc;
+  const int64_t j0 = (int64_t)c * p.SC;
+  const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
 
-  for (int64_t j0 = 0; j0 < p.nj; j0 += p.jc) {
-    const int jn = (int)((p.nj - j0 < p.jc) ? (p.nj - j0) : p.jc);
-    for (int j = tid; j < jn; j += blockDim.x) acc[j] = T(0);
-    if (LOO)
-      for (int j = tid; j < (jn + 31) / 32; j += blockDim.x) bits[j] = 0u;
-    __syncthreads();
+  for (int j = tid; j < p.SC; j += blockDim.x) acc[j] = T(0);
+  if (LOO)
+    for (int j = tid; j < (p.SC + 31) / 32; j += blockDim.x) bits[j] = 0u;
+  __syncthreads();
 
-    for (int t = 0; t < p.nterms; ++t) {
-      const CsrView<T> L = p.L[t];
-      const CsrView<T> M = p.M[t];
-      const int lb = L.ptr[gr], le = L.ptr[gr + 1];
-      for (int q = lb + wave; q < le; q += nwaves) {
-        const int a = L.idx[q];
-        const T lv = L.val[q];
-        T coef;
-        if (LOO) {
-          if (a == (int)gr) continue;  // the feature named after the query is not in the graph
-          const int d = p.kf[a] - 1;   // the query leaves every feature column it touched
-          coef = d > 0 ? lv * (T(1) / T(d)) : T(0);
-        } else {
-          coef = lv * p.inv1[t][a];
-        }
-        if (coef == T(0)) continue;
-        int mb = M.ptr[a], me = M.ptr[a + 1];
-        if (chunked) {
-          mb = lower_bound_dev(M.idx, mb, me, (int)j0);
-          me = lower_bound_dev(M.idx, mb, me, (int)(j0 + jn));
-        }
-        for (int x = mb + lane; x < me; x += 64) {
-          const int j = M.idx[x] - (int)j0;
-          atomicAdd(&acc[j], coef * M.val[x]);
+  for (int t = 0; t < p.nterms; ++t) {
+    const CsrView<T> L = p.L[t];
+    const ChunkedView<T> M = p.M[t];
+    const int* __restrict__ off = M.off + (int64_t)c * M.rows;
+    const unsigned short* __restrict__ midx = M.idx;
+    const T* __restrict__ mval = M.val;
+    const int lb = L.ptr[gr], le = L.ptr[gr + 1];
+    for (int q0 = lb + wave * U; q0 < le; q0 += nwaves * U) {
+      const int qs = __builtin_amdgcn_readfirstlane(q0);
+      int b[U], e[U];
+      T cf[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        b[u] = 0; e[u] = 0; cf[u] = T(0);
+        if (qs + u < le) {
+          const int a = L.idx[qs + u];
+          const T lv = L.val[qs + u];
+          if (LOO) {
+            const int d = p.kf[a] - 1;  // the query leaves every feature column it touched
+            cf[u] = (a != (int)gr && d > 0) ? lv * (T(1) / T(d)) : T(0);  // a == gr: the dropped feature
+          } else {
+            cf[u] = lv * p.inv1[t][a];
+          }
+          if (cf[u] != T(0)) { b[u] = off[a]; e[u] = off[a + 1]; }
         }
       }
+      int jj[U];
+      T vv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int x = b[u] + lane;
+        const bool ok = x < e[u];
+        jj[u] = ok ? (int)midx[x] : 0;
+        vv[u] = ok ? mval[x] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (b[u] + lane < e[u]) acc[jj[u]] = fma(cf[u], vv[u], acc[jj[u]]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        for (int x = b[u] + 64 + lane; x < e[u]; x += 64) {
+          const int j = midx[x];
+          acc[j] = fma(cf[u], mval[x], acc[j]);
+        }
     }
+  }
+  if (LOO) {
+    // sources that own the dropped feature column f_i: their degree is one lower in this fold
+    const ChunkedView<T> M = p.M[0];
+    const int* off = M.off + (int64_t)c * M.rows;
+    for (int x = off[gr] + tid; x < off[gr + 1]; x += blockDim.x) {
+      const int j = M.idx[x];
+      atomicOr(&bits[j >> 5], 1u << (j & 31));
+    }
+  }
+  __syncthreads();
+
+  T* orow = p.out + r * p.ld + j0;
+  for (int j = tid; j < jn; j += blockDim.x) {
+    T z;
     if (LOO) {
-      // sources that own the dropped feature column f_i: their degree is one lower in this fold
-      const CsrView<T> M = p.M[0];
-      int mb = M.ptr[gr], me = M.ptr[gr + 1];
-      if (chunked) {
-        mb = lower_bound_dev(M.idx, mb, me, (int)j0);
-        me = lower_bound_dev(M.idx, mb, me, (int)(j0 + jn));
-      }
-      for (int x = mb + tid; x < me; x += blockDim.x) {
-        const int j = M.idx[x] - (int)j0;
-        atomicOr(&bits[j >> 5], 1u << (j & 31));
-      }
+      const int d = p.ks[j0 + j] - (int)((bits[j >> 5] >> (j & 31)) & 1u);
+      z = (d > 0 && (j0 + j) != gr) ? acc[j] * (T(1) / T(d)) : T(0);
+    } else {
+      z = acc[j] * p.inv2[j0 + j];
     }
-    __syncthreads();
-
-    T* orow = p.out + r * p.ld + j0;
-    for (int j = tid; j < jn; j += blockDim.x) {
-      T z;
-      if (LOO) {
-        const int d = p.ks[j0 + j] - (int)((bits[j >> 5] >> (j & 31)) & 1u);
-        z = (d > 0 && (j0 + j) != gr) ? acc[j] * (T(1) / T(d)) : T(0);
-      } else {
-        z = acc[j] * p.inv2[j0 + j];
-      }
-      orow[j] = z;
-    }
-    __syncthreads();
+    orow[j] = z;
   }
 }
 
-template <class T>
-static int transfer_chunk(int64_t nj, bool loo) {
-  // LDS budget per workgroup: keep >= 2 workgroups per CU when the row is long
-  const int64_t budget = 64 * 1024;
-  int64_t jc = budget / (int64_t)sizeof(T);
-  if (loo) jc = (budget * 32) / (32 * (int64_t)sizeof(T) + 4);
-  jc &= ~63LL;
-  if (nj <= jc) jc = (nj + 63) & ~63LL;
-  return (int)jc;
-}
+constexpr int TRANSFER_U = 4;
 
 template <class T>
-int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevCsr<T>* Mt[2],
+int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
                     const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld) {
   if (nrows <= 0 || nj <= 0) return SS_OK;
   TransferArgs<T> p{};
@@ -217,21 +236,27 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
     p.L[t] = view(*L[t]);
     p.M[t] = view(*Mt[t]);
     p.inv1[t] = inv1[t];
+    if (Mt[t]->SC != Mt[0]->SC || Mt[t]->nchunks != Mt[0]->nchunks)
+      return fail(SS_EINVAL, "transfer operands were cut with different chunk sizes");
   }
   p.inv2 = inv2;
   p.row_begin = row_begin;
   p.nj = nj;
-  p.jc = transfer_chunk<T>(nj, false);
+  p.SC = Mt[0]->SC;
+  p.nchunks = Mt[0]->nchunks;
   p.out = out;
   p.ld = ld;
-  const size_t lds = (size_t)p.jc * sizeof(T);
-  hipLaunchKernelGGL((transfer_kernel<T, false>), dim3((unsigned)nrows), dim3(256), lds, ctx().stream, p);
+  const int64_t grid = nrows * p.nchunks;
+  if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
+  const size_t lds = (size_t)p.SC * sizeof(T);
+  hipLaunchKernelGGL((transfer_kernel<T, false, TRANSFER_U>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
+                     ctx().stream, p);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
 
 template <class T>
-int launch_transfer_loo(const DevCsr<T>& X, const DevCsr<T>& XT, const int* kf, const int* ks,
+int launch_transfer_loo(const DevCsr<T>& X, const DevChunked<T>& XT, const int* kf, const int* ks,
                         int64_t i_begin, int64_t nrows, T* out, int64_t ld) {
   if (nrows <= 0) return SS_OK;
   TransferArgs<T> p{};
@@ -242,11 +267,15 @@ int launch_transfer_loo(const DevCsr<T>& X, const DevCsr<T>& XT, const int* kf, 
   p.ks = ks;
   p.row_begin = i_begin;
   p.nj = X.rows;
-  p.jc = transfer_chunk<T>(p.nj, true);
+  p.SC = XT.SC;
+  p.nchunks = XT.nchunks;
   p.out = out;
   p.ld = ld;
-  const size_t lds = (size_t)p.jc * sizeof(T) + (size_t)((p.jc + 31) / 32) * 4;
-  hipLaunchKernelGGL((transfer_kernel<T, true>), dim3((unsigned)nrows), dim3(256), lds, ctx().stream, p);
+  const int64_t grid = nrows * p.nchunks;
+  if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
+  const size_t lds = (size_t)p.SC * sizeof(T) + (size_t)((p.SC + 31) / 32) * 4;
+  hipLaunchKernelGGL((transfer_kernel<T, true, TRANSFER_U>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
+                     ctx().stream, p);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
@@ -525,10 +554,10 @@ int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, i
   template int launch_cutoff<T>(const T*, int64_t, int64_t, int64_t, T, bool, T*, int64_t);                 \
   template int launch_row_degree<T>(const T*, int64_t, int64_t, int64_t, int*);                             \
   template int launch_spread_dense<T>(const T*, int64_t, int64_t, int64_t, const int*, T*, int64_t);        \
-  template int launch_transfer<T>(int, const DevCsr<T>*[2], const T*[2], const DevCsr<T>*[2], const T*,     \
+  template int launch_transfer<T>(int, const DevCsr<T>*[2], const T*[2], const DevChunked<T>*[2], const T*, \
                                   int64_t, int64_t, int64_t, T*, int64_t);                                  \
-  template int launch_transfer_loo<T>(const DevCsr<T>&, const DevCsr<T>&, const int*, const int*, int64_t,  \
-                                      int64_t, T*, int64_t);                                                \
+  template int launch_transfer_loo<T>(const DevCsr<T>&, const DevChunked<T>&, const int*, const int*,       \
+                                      int64_t, int64_t, T*, int64_t);                                                \
   template int sell_max_chunk<T>(int);                                                                      \
   template int launch_spmm_sell<T>(const DevSell<T>&, const T*, int64_t, int64_t, T*, int64_t, const int*); \
   template int launch_spmm_csr_narrow<T>(const DevCsr<T>&, const T*, int64_t, int, T*, int64_t);            \
