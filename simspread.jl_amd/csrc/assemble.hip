@@ -549,8 +549,11 @@ int chunked_build(const DevCsr<T>& in, int SC, DevChunked<T>& out) {
   out.nchunks = (int)(in.cols > 0 ? ceil_div(in.cols, SC) : 1);
   const int64_t total = in.rows * out.nchunks;
   SS_TRY(out.off.alloc(total + 1));
-  SS_TRY(out.idx.alloc(in.nnz));
-  SS_TRY(out.val.alloc(in.nnz));
+  // 64 entries of slack: the transfer kernel loads whole waves past the end of a sub-row
+  SS_TRY(out.idx.alloc(in.nnz + 64));
+  SS_TRY(out.val.alloc(in.nnz + 64));
+  SS_HIP(hipMemsetAsync(out.idx.p, 0, (in.nnz + 64) * sizeof(unsigned short), st));
+  SS_HIP(hipMemsetAsync(out.val.p, 0, (in.nnz + 64) * sizeof(T), st));
   if (total == 0) {
     SS_HIP(hipMemsetAsync(out.off.p, 0, sizeof(int), st));
     return SS_OK;

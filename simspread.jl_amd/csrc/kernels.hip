@@ -137,21 +137,93 @@ struct TransferArgs {
 // (tools/lds_atomic_bench.hip) -- which is why this is not an LDS-atomic kernel.
 constexpr int TRANSFER_THREADS = 64;
 
+template <class T> struct BitsOf;
+template <> struct BitsOf<float> {
+  static __device__ __forceinline__ float bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+  }
+};
+template <> struct BitsOf<double> {
+  static __device__ __forceinline__ double bcast(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+};
+
+// U sub-rows: scalar bounds + coefficient, and the (unconditional) loads of their first 64 entries.
+// The operand arrays carry 64 entries of slack, so lanes past the end of a sub-row read valid memory;
+// such lanes are steered to a per-lane dummy accumulator behind the chunk.
+template <class T, int U>
+struct SubRows {
+  int n[U];
+  unsigned b[U];
+  T cf[U];
+  unsigned short j[U];
+  T v[U];
+};
+
+template <class T, int U>
+__device__ __forceinline__ void subrows_load(SubRows<T, U>& s, int first, int b_l, int n_l, T cf_l,
+                                             const unsigned short* __restrict__ midx, const T* __restrict__ mval,
+                                             int lane) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int src = first + u;  // < 64 by construction
+    s.b[u] = (unsigned)__builtin_amdgcn_readlane(b_l, src);
+    s.n[u] = __builtin_amdgcn_readlane(n_l, src);
+    s.cf[u] = BitsOf<T>::bcast(cf_l, src);
+    const unsigned short* pi = midx + s.b[u];
+    const T* pv = mval + s.b[u];
+    s.j[u] = pi[lane];
+    s.v[u] = pv[lane];
+  }
+}
+
+template <class T, int U>
+__device__ __forceinline__ void subrows_fold(const SubRows<T, U>& s, int first, int b_l, int n_l, T cf_l,
+                                             T* __restrict__ acc, int dummy,
+                                             const unsigned short* __restrict__ midx, const T* __restrict__ mval,
+                                             int lane) {
+  int nmax = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int j = lane < s.n[u] ? (int)s.j[u] : dummy;
+    acc[j] = fma(s.cf[u], s.v[u], acc[j]);
+    nmax = s.n[u] > nmax ? s.n[u] : nmax;
+  }
+  if (nmax > 64) {  // rare: a sub-row longer than one wave (bounds re-read by lane index, no register arrays)
+#pragma unroll 1
+    for (int u = 0; u < U; ++u) {
+      const int n = __builtin_amdgcn_readlane(n_l, first + u);
+      const unsigned b = (unsigned)__builtin_amdgcn_readlane(b_l, first + u);
+      const T cf = BitsOf<T>::bcast(cf_l, first + u);
+      for (int x = 64 + lane; x < n; x += 64) {
+        const int j = midx[b + x];
+        acc[j] = fma(cf, mval[b + x], acc[j]);
+      }
+    }
+  }
+}
+
 template <class T, bool LOO, int U>
 __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs<T> p) {
+  static_assert(64 % (2 * U) == 0, "U must divide 32");
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* acc = reinterpret_cast<T*>(smem_raw);
-  unsigned* bits = reinterpret_cast<unsigned*>(acc + p.SC);  // LOO only: source owns the dropped feature
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  T* acc = reinterpret_cast<T*>(smem_raw);                        // [SC] sums + [64] per-lane dummies
+  unsigned* bits = reinterpret_cast<unsigned*>(acc + p.SC + 64);  // LOO only: source owns the dropped feature
+  const int lane = threadIdx.x;
   const int c = blockIdx.x % p.nchunks;
   const int64_t r = blockIdx.x / p.nchunks;
   const int64_t gr = p.row_begin + r;
   const int64_t j0 = (int64_t)c * p.SC;
   const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
+  const int dummy = p.SC + lane;
 
-  for (int j = tid; j < p.SC; j += blockDim.x) acc[j] = T(0);
+  for (int j = lane; j < p.SC + 64; j += 64) acc[j] = T(0);
   if (LOO)
-    for (int j = tid; j < (p.SC + 31) / 32; j += blockDim.x) bits[j] = 0u;
+    for (int j = lane; j < (p.SC + 31) / 32; j += 64) bits[j] = 0u;
   __syncthreads();
 
   for (int t = 0; t < p.nterms; ++t) {
@@ -161,50 +233,41 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
     const unsigned short* __restrict__ midx = M.idx;
     const T* __restrict__ mval = M.val;
     const int lb = L.ptr[gr], le = L.ptr[gr + 1];
-    for (int q0 = lb + wave * U; q0 < le; q0 += nwaves * U) {
-      const int qs = __builtin_amdgcn_readfirstlane(q0);
-      int b[U], e[U];
-      T cf[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        b[u] = 0; e[u] = 0; cf[u] = T(0);
-        if (qs + u < le) {
-          const int a = L.idx[qs + u];
-          const T lv = L.val[qs + u];
-          if (LOO) {
-            const int d = p.kf[a] - 1;  // the query leaves every feature column it touched
-            cf[u] = (a != (int)gr && d > 0) ? lv * (T(1) / T(d)) : T(0);  // a == gr: the dropped feature
-          } else {
-            cf[u] = lv * p.inv1[t][a];
-          }
-          if (cf[u] != T(0)) { b[u] = off[a]; e[u] = off[a + 1]; }
+    for (int g0 = lb; g0 < le; g0 += 64) {
+      // ---- the next 64 neighbours a of r, one per lane: coefficient and sub-row bounds
+      const int q = g0 + lane;
+      int b_l = 0, n_l = 0;
+      T cf_l = T(0);
+      if (q < le) {
+        const int a = L.idx[q];
+        const T lv = L.val[q];
+        if (LOO) {
+          const int d = p.kf[a] - 1;  // the query leaves every feature column it touched
+          cf_l = (a != (int)gr && d > 0) ? lv * (T(1) / T(d)) : T(0);  // a == gr: the dropped feature
+        } else {
+          cf_l = lv * p.inv1[t][a];
+        }
+        if (cf_l != T(0)) { b_l = off[a]; n_l = off[a + 1] - b_l; }
+      }
+      const int cnt = __builtin_amdgcn_readfirstlane((le - g0 < 64) ? (le - g0) : 64);
+      // ---- fold the sub-rows in, U at a time; the loads of the next U are in flight meanwhile
+      SubRows<T, U> A, B;
+      subrows_load<T, U>(A, 0, b_l, n_l, cf_l, midx, mval, lane);
+      for (int u0 = 0; u0 < cnt; u0 += 2 * U) {
+        if (u0 + U < cnt) subrows_load<T, U>(B, u0 + U, b_l, n_l, cf_l, midx, mval, lane);
+        subrows_fold<T, U>(A, u0, b_l, n_l, cf_l, acc, dummy, midx, mval, lane);
+        if (u0 + U < cnt) {
+          if (u0 + 2 * U < cnt) subrows_load<T, U>(A, u0 + 2 * U, b_l, n_l, cf_l, midx, mval, lane);
+          subrows_fold<T, U>(B, u0 + U, b_l, n_l, cf_l, acc, dummy, midx, mval, lane);
         }
       }
-      int jj[U];
-      T vv[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int x = b[u] + lane;
-        const bool ok = x < e[u];
-        jj[u] = ok ? (int)midx[x] : 0;
-        vv[u] = ok ? mval[x] : T(0);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (b[u] + lane < e[u]) acc[jj[u]] = fma(cf[u], vv[u], acc[jj[u]]);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        for (int x = b[u] + 64 + lane; x < e[u]; x += 64) {
-          const int j = midx[x];
-          acc[j] = fma(cf[u], mval[x], acc[j]);
-        }
     }
   }
   if (LOO) {
     // sources that own the dropped feature column f_i: their degree is one lower in this fold
     const ChunkedView<T> M = p.M[0];
     const int* off = M.off + (int64_t)c * M.rows;
-    for (int x = off[gr] + tid; x < off[gr + 1]; x += blockDim.x) {
+    for (int x = off[gr] + lane; x < off[gr + 1]; x += 64) {
       const int j = M.idx[x];
       atomicOr(&bits[j >> 5], 1u << (j & 31));
     }
@@ -212,7 +275,7 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
   __syncthreads();
 
   T* orow = p.out + r * p.ld + j0;
-  for (int j = tid; j < jn; j += blockDim.x) {
+  for (int j = lane; j < jn; j += 64) {
     T z;
     if (LOO) {
       const int d = p.ks[j0 + j] - (int)((bits[j >> 5] >> (j & 31)) & 1u);
@@ -224,7 +287,7 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
   }
 }
 
-constexpr int TRANSFER_U = 4;
+constexpr int TRANSFER_U = 8;
 
 template <class T>
 int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
@@ -248,7 +311,7 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
   p.ld = ld;
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
-  const size_t lds = (size_t)p.SC * sizeof(T);
+  const size_t lds = (size_t)(p.SC + 64) * sizeof(T);
   hipLaunchKernelGGL((transfer_kernel<T, false, TRANSFER_U>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
                      ctx().stream, p);
   SS_LAUNCH_CHECK();
@@ -273,7 +336,7 @@ int launch_transfer_loo(const DevCsr<T>& X, const DevChunked<T>& XT, const int* 
   p.ld = ld;
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
-  const size_t lds = (size_t)p.SC * sizeof(T) + (size_t)((p.SC + 31) / 32) * 4;
+  const size_t lds = (size_t)(p.SC + 64) * sizeof(T) + (size_t)((p.SC + 31) / 32) * 4;
   hipLaunchKernelGGL((transfer_kernel<T, true, TRANSFER_U>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
                      ctx().stream, p);
   SS_LAUNCH_CHECK();
