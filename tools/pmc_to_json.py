@@ -1,0 +1,32 @@
+"""Turn a gpurun_out/prof_<tag> directory (tools/profile.sh) into profiles/pmc_<tag>.json + pmc_latest.json."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def avg(counter_dir, counter):
+    agg = defaultdict(list)
+    for f in glob.glob(os.path.join(src, counter_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] == counter:
+                    agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+fetch, write = avg("pmc_FETCH_SIZE", "FETCH_SIZE"), avg("pmc_WRITE_SIZE", "WRITE_SIZE")
+dur = defaultdict(list)
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 5 --warmup 2`",
+       "units": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
+       "kernels": {}}
+for k in fetch:
+    if not any(s in k for s in ("transfer_kernel", "spmm_sell", "spmm_csr")):
+        continue
+    out["kernels"][k] = {"FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write.get(k),
+                         "hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0)) * 1024,
+                         "avg_duration_us": (sum(dur[k]) / len(dur[k]) / 1e3) if k in dur else None}
+for name in (f"pmc_{tag}.json", "pmc_latest.json"):
+    with open(os.path.join(root, "profiles", name), "w") as f:
+        json.dump(out, f, indent=1)
+print(json.dumps(out, indent=1))
