@@ -138,6 +138,7 @@ def main():
 
     import simspread_jl_amd as ss
     ss.init(local_rank)
+    ss.use_torch_stream()  # device buffers come from torch: share its stream
 
     nq, n = args.nq, args.n
     Xq, Xs, Ys = synth_c2(nq, n, n, n, args.dx, args.dy, seed=20250222 + 2, rank=rank)

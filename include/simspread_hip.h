@@ -64,6 +64,12 @@ int ss_device_count(void);
  * reference's `GPU::Bool` switch (src/core.jl:402,404,446,448). */
 int ss_init(int device);
 int ss_shutdown(void);
+/* Run on the caller's HIP stream (e.g. torch's current stream) so that kernels that produced
+ * SS_MEM_DEVICE inputs are ordered before the library's.  NULL is HIP's null (default) stream.
+ * The caller keeps ownership of the stream.  ss_reset_stream() returns to the library's own
+ * (non-blocking) stream. */
+int ss_set_stream(void* hip_stream);
+int ss_reset_stream(void);
 int ss_synchronize(void);
 /* Timings of the last predict/spmm call, milliseconds, measured with hipEvents on the
  * library stream: ms[0] whole call on device, [1] transfer stage (stage 1), [2] W*R SpMM

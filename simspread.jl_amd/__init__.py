@@ -5,10 +5,10 @@ The hot path ``featurize -> construct -> spread -> predict -> clean!`` of cvigil
 kernels in ``libsimspread_hip.so`` (C ABI: include/simspread_hip.h).  No CPU fallback.
 """
 from . import _lib
-from ._lib import SimSpreadError, init, timing_last
+from ._lib import SimSpreadError, init, timing_last, use_torch_stream
 from .core import (NamedMatrix, Network, clean, clean_, construct, cutoff, featurize, k, names, predict, spread)
 from .dist import gather_scores, shard_range
 from .engine import DeviceGraph, DeviceSpMat
 
-__all__ = ["NamedMatrix", "Network", "DeviceGraph", "DeviceSpMat", "SimSpreadError", "init", "timing_last",
+__all__ = ["NamedMatrix", "Network", "DeviceGraph", "DeviceSpMat", "SimSpreadError", "init", "timing_last", "use_torch_stream",
            "shard_range", "gather_scores", "k", "cutoff", "featurize", "construct", "spread", "predict", "clean", "clean_", "names"]

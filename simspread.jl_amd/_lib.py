@@ -43,6 +43,8 @@ def _sigs():
         "ss_device_count": ([], _int),
         "ss_init": ([_int], _int),
         "ss_shutdown": ([], _int),
+        "ss_set_stream": ([_vp], _int),
+        "ss_reset_stream": ([], _int),
         "ss_synchronize": ([], _int),
         "ss_timing_last": ([_vp, _int], _int),
         "ss_graph_destroy": ([_vp], _int),
@@ -115,6 +117,13 @@ def init(device: int | None = None):
 def lib():
     """The initialised library; the compute paths call this, so they fail loudly without a GPU."""
     return init()
+
+
+def use_torch_stream():
+    """Enqueue on torch's current stream: required whenever torch CUDA tensors are handed over by
+    pointer, so that the kernels that produced them are ordered before the library's."""
+    import torch
+    check(lib().ss_set_stream(torch.cuda.current_stream().cuda_stream))
 
 
 def timing_last():

@@ -291,9 +291,9 @@ static int graph_chunked(Graph<T>& g, bool need_y) {
     int64_t nch = ceil_div(ns, sc);
     if (nch > 1) nch = ceil_div(nch, 8) * 8;
     sc = ceil_div(ceil_div(ns, nch), 4) * 4;
-    SS_TRY(chunked_build<T>(g.XsT, (int)sc, g.XsTc));
+    SS_TRY(chunked_build<T>(g.XsT, (int)sc, 1, g.XsTc));
   }
-  if (need_y && g.YsTc.SC == 0) SS_TRY(chunked_build<T>(g.YsT, g.XsTc.SC, g.YsTc));
+  if (need_y && g.YsTc.SC == 0) SS_TRY(chunked_build<T>(g.YsT, g.XsTc.SC, 1, g.YsTc));
   return SS_OK;
 }
 
@@ -498,7 +498,24 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   SS_TRY(timing_mark(&e_begin));
   const bool narrow = (B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR);
   DevBuf<T> Rt, Ft;
-  if (narrow) {
+  const bool use_csr_gather = getenv("SS_NARROW_CSR") != nullptr;
+  if (narrow && B <= 16 && !use_csr_gather) {
+    // R chunk resident in LDS, W streamed once in chunk-major order (HBM-bound regime)
+    int slot = 0, bv = 1;
+    while (bv < B) { bv <<= 1; ++slot; }
+    DevChunked<T>& op = m.narrow[slot];
+    if (op.SC == 0) {
+      int kc = narrow_chunk_cols<T>(bv);
+      if (const char* e = getenv("SS_NARROW_CHUNK")) {
+        const int v = atoi(e);
+        if (v >= 16 && v < kc) kc = v;
+      }
+      SS_TRY(chunked_build<T>(m.csr, kc, 4, op));
+    }
+    StageTimer t2(ST_SPMM);
+    SS_TRY(launch_spmm_chunked_narrow<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
+    timing_count(ST_NSPMM, 1);
+  } else if (narrow) {
     StageTimer t2(ST_SPMM);
     SS_TRY(launch_spmm_csr_narrow<T>(m.csr, Rd, ldr_d, (int)B, Fd, ldf_d));
     timing_count(ST_NSPMM, 1);
@@ -583,7 +600,8 @@ int ss_init(int device) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(SS_ENODEV, "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
   c.num_cu = prop.multiProcessorCount;
-  SS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  SS_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+  c.stream = c.own_stream;
   c.device = device;
   c.inited = true;
   return SS_OK;
@@ -597,10 +615,27 @@ int ss_shutdown(void) {
   c.timing.pool.clear();
   c.timing.spans.clear();
   c.timing.used = 0;
-  (void)hipStreamDestroy(c.stream);
+  (void)hipStreamDestroy(c.own_stream);
+  c.own_stream = nullptr;
   c.stream = nullptr;
   c.inited = false;
   c.device = -1;
+  return SS_OK;
+}
+
+int ss_set_stream(void* hip_stream) {
+  SS_TRY(require_init());
+  Ctx& c = ctx();
+  SS_HIP(hipStreamSynchronize(c.stream));
+  c.stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the null stream
+  return SS_OK;
+}
+
+int ss_reset_stream(void) {
+  SS_TRY(require_init());
+  Ctx& c = ctx();
+  SS_HIP(hipStreamSynchronize(c.stream));
+  c.stream = c.own_stream;
   return SS_OK;
 }
 

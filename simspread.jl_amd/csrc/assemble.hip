@@ -497,7 +497,7 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
 // ------------------------------------------------------------------ CSR -> column-chunked CSR (stage-1 operand)
 // one thread per (chunk, row): entries of the row inside the chunk
 __global__ void chunk_count_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, int64_t rows, int SC,
-                                   int nchunks, int* __restrict__ cnt) {
+                                   int nchunks, int align, int* __restrict__ cnt) {
   const int64_t total = rows * nchunks;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i / rows);
@@ -509,14 +509,14 @@ __global__ void chunk_count_kernel(const int* __restrict__ ptr, const int* __res
     const int first = a;
     b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
-    cnt[i] = a - first;
+    cnt[i] = (a - first + align - 1) / align;  // in units of `align` entries
   }
 }
 
-// wave per (chunk, row): copy the sub-row with chunk-local indices
+// wave per (chunk, row): copy the sub-row with chunk-local indices, padded to whole units
 template <class T>
 __global__ void chunk_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
-                                  int64_t rows, int SC, int nchunks, const int* __restrict__ off,
+                                  int64_t rows, int SC, int nchunks, int align, const int* __restrict__ off,
                                   unsigned short* __restrict__ oidx, T* __restrict__ oval) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -525,47 +525,62 @@ __global__ void chunk_fill_kernel(const int* __restrict__ ptr, const int* __rest
   for (int64_t i = wave0; i < total; i += nwaves) {
     const int c = (int)(i / rows);
     const int64_t r = i - (int64_t)c * rows;
-    const int o = off[i], n = off[i + 1] - o;
-    if (n == 0) continue;
+    const int64_t o = (int64_t)off[i] * align;
+    const int npad = (off[i + 1] - off[i]) * align;
+    if (npad == 0) continue;
     const int lo = ptr[r], hi = ptr[r + 1];
-    const int64_t k0 = (int64_t)c * SC;
+    const int64_t k0 = (int64_t)c * SC, k1 = k0 + SC;
     int a = lo, b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
-    for (int x = lane; x < n; x += 64) {
-      oidx[o + x] = (unsigned short)(idx[a + x] - k0);
-      oval[o + x] = val[a + x];
+    const int first = a;
+    b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
+    const int n = a - first;
+    for (int x = lane; x < npad; x += 64) {
+      oidx[o + x] = x < n ? (unsigned short)(idx[first + x] - k0) : (unsigned short)SC;  // SC = zero sentinel
+      oval[o + x] = x < n ? val[first + x] : T(0);
     }
   }
 }
 
 template <class T>
-int chunked_build(const DevCsr<T>& in, int SC, DevChunked<T>& out) {
+int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out) {
   hipStream_t st = ctx().stream;
-  if (SC < 1 || SC > 65536) return fail(SS_EINVAL, "transfer chunk size out of range");
+  if (SC < 1 || SC > 65535) return fail(SS_EINVAL, "chunk size out of range");
+  if (align != 1 && align != 4) return fail(SS_EINVAL, "chunk alignment must be 1 or 4");
   out.rows = in.rows;
   out.cols = in.cols;
   out.nnz = in.nnz;
   out.SC = SC;
+  out.align = align;
   out.nchunks = (int)(in.cols > 0 ? ceil_div(in.cols, SC) : 1);
   const int64_t total = in.rows * out.nchunks;
   SS_TRY(out.off.alloc(total + 1));
-  // 64 entries of slack: the transfer kernel loads whole waves past the end of a sub-row
-  SS_TRY(out.idx.alloc(in.nnz + 64));
-  SS_TRY(out.val.alloc(in.nnz + 64));
-  SS_HIP(hipMemsetAsync(out.idx.p, 0, (in.nnz + 64) * sizeof(unsigned short), st));
-  SS_HIP(hipMemsetAsync(out.val.p, 0, (in.nnz + 64) * sizeof(T), st));
   if (total == 0) {
     SS_HIP(hipMemsetAsync(out.off.p, 0, sizeof(int), st));
+    SS_TRY(out.idx.alloc(64));
+    SS_TRY(out.val.alloc(64));
+    SS_HIP(hipMemsetAsync(out.idx.p, 0, 64 * sizeof(unsigned short), st));
+    SS_HIP(hipMemsetAsync(out.val.p, 0, 64 * sizeof(T), st));
     return SS_OK;
   }
   DevBuf<int> cnt;
   SS_TRY(cnt.alloc(total));
   hipLaunchKernelGGL(chunk_count_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p, in.rows, SC,
-                     out.nchunks, cnt.p);
+                     out.nchunks, align, cnt.p);
   SS_LAUNCH_CHECK();
   SS_TRY(exclusive_scan_int(cnt.p, out.off.p, total));
+  int units = 0;
+  SS_TRY(read_int(out.off.p + total, &units));
+  if (units < 0 || (int64_t)units * align >= (1LL << 31) - 64) return fail(SS_EUNSUPPORTED, "chunked operand too large");
+  out.stored = (int64_t)units * align;
+  // 64 entries of slack: the transfer kernel loads whole waves past the end of a sub-row
+  SS_TRY(out.idx.alloc(out.stored + 64));
+  SS_TRY(out.val.alloc(out.stored + 64));
+  SS_HIP(hipMemsetAsync(out.idx.p + out.stored, 0, 64 * sizeof(unsigned short), st));
+  SS_HIP(hipMemsetAsync(out.val.p + out.stored, 0, 64 * sizeof(T), st));
   hipLaunchKernelGGL(chunk_fill_kernel<T>, dim3(grid_for(total * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p,
-                     in.val.p, in.rows, SC, out.nchunks, out.off.p, out.idx.p, out.val.p);
+                     in.val.p, in.rows, SC, out.nchunks, align, out.off.p, out.idx.p, out.val.p);
   SS_LAUNCH_CHECK();
   SS_HIP(hipStreamSynchronize(st));
   return SS_OK;
@@ -645,7 +660,7 @@ int graph_finalize_general(Graph<T>& g) {
   template int csr_from_user<T>(int64_t, int64_t, const int64_t*, const int32_t*, const T*, int, int, DevCsr<T>&); \
   template int csr_from_dense<T>(const T*, int64_t, int64_t, int64_t, bool, T, bool, int, DevCsr<T>&);         \
   template int csr_transpose<T>(const DevCsr<T>&, DevCsr<T>&);                                                 \
-  template int chunked_build<T>(const DevCsr<T>&, int, DevChunked<T>&);                                        \
+  template int chunked_build<T>(const DevCsr<T>&, int, int, DevChunked<T>&);                                     \
   template int sell_build<T>(const DevCsr<T>&, int, DevSell<T>&);                                              \
   template int graph_finalize<T>(Graph<T>&);                                                                   \
   template int graph_finalize_general<T>(Graph<T>&);

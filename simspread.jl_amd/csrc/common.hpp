@@ -49,7 +49,8 @@ struct Timing {
 struct Ctx {
   bool inited = false;
   int device = -1;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream everything is enqueued on
+  hipStream_t own_stream = nullptr;  // created by ss_init; `stream` may point at a caller's stream instead
   int num_cu = 256;
   size_t lds_per_block = 160 * 1024;
   Timing timing;

@@ -40,10 +40,13 @@ struct DevSell {
 template <class T>
 struct DevChunked {
   int64_t rows = 0, cols = 0, nnz = 0;
+  int64_t stored = 0;          // entries incl. padding
   int SC = 0, nchunks = 0;
+  int align = 1;               // sub-rows padded to whole units of `align` entries; off[] counts units.
+                               // Padding entries carry local index SC (a zero operand row) and value 0.
   DevBuf<int> off;             // [nchunks*rows + 1]
-  DevBuf<unsigned short> idx;  // [nnz]
-  DevBuf<T> val;               // [nnz]
+  DevBuf<unsigned short> idx;  // [stored + 64]
+  DevBuf<T> val;               // [stored + 64]
 };
 
 template <class T>
@@ -69,6 +72,8 @@ struct SpMat {
   DevCsr<T> csr;
   DevSell<T> sell;
   int sell_qt = 0;
+  DevChunked<T> narrow[5];  // quad-aligned chunked operands for B <= 1, 2, 4, 8, 16 (built lazily)
+  DevBuf<T> partial;        // [nchunks][rows][BV] partial sums of the narrow kernel
 };
 
 // ---- assemble.hip
@@ -83,7 +88,7 @@ int csr_transpose(const DevCsr<T>& in, DevCsr<T>& out);
 template <class T>
 int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out);
 template <class T>
-int chunked_build(const DevCsr<T>& in, int SC, DevChunked<T>& out);
+int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out);
 template <class T>
 int graph_finalize(Graph<T>& g);  // transposes + degrees
 template <class T>
@@ -124,6 +129,12 @@ int sell_max_chunk(int qt);
 template <class T>
 int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T* F, int64_t ldf,
                      const int* clean_deg);
+// stage 2, narrow (B <= 16): R chunk in LDS, W streamed once from HBM in chunk-major order
+template <class T>
+int narrow_chunk_cols(int bv);  // KC for a padded width bv
+template <class T>
+int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
+                               DevBuf<T>& partial);
 // stage 2, narrow (B <= 64): F[m][b] = sum_k W[m][k] * R[k][b]   (row-major operands, CSR streamed once)
 template <class T>
 int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);

@@ -560,6 +560,289 @@ int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T
   return SS_OK;
 }
 
+// ============================================================== stage 2, narrow, HBM-bound: R chunk in LDS
+// F = W*R for B <= 16 columns.  W is cut into column chunks of KC (all of R's rows k0..k0+KC for the B
+// columns fit in LDS), stored chunk-major with 16-bit local indices, sub-rows padded to 4 entries so
+// that a lane streams 8 B of indices + 16 B of values per step; workgroup (c, slot) keeps chunk c of R
+// in LDS and walks every nslots-th group of 16 rows, one wave per sub-row, __shfl_xor to fold the lanes.
+// Every non-zero of W is read exactly once from HBM (6 B instead of CSR's 8 B); partial sums per chunk
+// are combined in fixed order by narrow_reduce_kernel.
+template <class T>
+struct NarrowArgs {
+  const int* off;
+  const unsigned short* idx;
+  const T* val;
+  int64_t M, K;
+  int KC, nchunks, B;
+  const T* R;
+  int64_t ldr;
+  T* F;       // direct output when nchunks == 1
+  int64_t ldf;
+  T* P;       // [nchunks][M][BV] otherwise
+};
+
+constexpr int NARROW_THREADS = 1024;
+
+// GL = lanes that share one sub-row (64, 32, 16 or 8: the power of two above the mean sub-row length in
+// quads), so a wave streams 64/GL rows at once; UR row groups are unrolled to keep more loads in flight.
+template <class T, int VEC, int LPN, int GL, int UR>
+__global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(NarrowArgs<T> a) {
+  constexpr int BV = VEC * LPN;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);  // [KC + 1][BV]; row KC stays zero (padding target)
+  using V = Vec<T, VEC>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int c = blockIdx.x % a.nchunks;
+  const int slot = blockIdx.x / a.nchunks, nslots = gridDim.x / a.nchunks;
+  const int64_t k0 = (int64_t)c * a.KC;
+  const int kn = (int)((a.K - k0 < a.KC) ? (a.K - k0) : a.KC);
+
+  for (int e = tid; e < (a.KC + 1) * BV; e += blockDim.x) {
+    const int k = e / BV, b = e - k * BV;
+    tile[e] = (k < kn && b < a.B) ? a.R[(k0 + k) * a.ldr + b] : T(0);
+  }
+  __syncthreads();
+
+  const int* __restrict__ off = a.off + (int64_t)c * a.M;
+  if (LPN == 1) {
+    constexpr int RPS = 64 / GL;  // rows per wave-step
+    const int sub = lane / GL, gl = lane % GL;
+    const ushort4* __restrict__ ip = reinterpret_cast<const ushort4*>(a.idx);
+    const Vec<T, 4>* __restrict__ vp = reinterpret_cast<const Vec<T, 4>*>(a.val);
+    const int64_t stride = (int64_t)nslots * nwaves * RPS * UR;
+    for (int64_t mb = ((int64_t)slot * nwaves + wave) * RPS * UR; mb < a.M; mb += stride) {
+      int o[UR], oe[UR];
+      ushort4 iv[UR];
+      Vec<T, 4> w[UR];
+      T acc[UR][VEC];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int64_t m = mb + u * RPS + sub;
+        o[u] = m < a.M ? off[m] : 0;
+        oe[u] = m < a.M ? off[m + 1] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int q = o[u] + gl;
+        const int qq = q < oe[u] ? q : o[u];  // a valid address; masked below
+        iv[u] = ip[qq];
+        w[u] = vp[qq];
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const bool has = o[u] + gl < oe[u];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[u][i] = T(0);
+        if (has) {
+          const V r0 = *reinterpret_cast<const V*>(&tile[(int)iv[u].x * BV]);
+          const V r1 = *reinterpret_cast<const V*>(&tile[(int)iv[u].y * BV]);
+          const V r2 = *reinterpret_cast<const V*>(&tile[(int)iv[u].z * BV]);
+          const V r3 = *reinterpret_cast<const V*>(&tile[(int)iv[u].w * BV]);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            acc[u][i] = fma(w[u].v[0], r0.v[i], acc[u][i]);
+            acc[u][i] = fma(w[u].v[1], r1.v[i], acc[u][i]);
+            acc[u][i] = fma(w[u].v[2], r2.v[i], acc[u][i]);
+            acc[u][i] = fma(w[u].v[3], r3.v[i], acc[u][i]);
+          }
+        }
+        for (int q = o[u] + gl + GL; q < oe[u]; q += GL) {  // sub-rows longer than one group step
+          const ushort4 jv = ip[q];
+          const Vec<T, 4> x = vp[q];
+          const V r0 = *reinterpret_cast<const V*>(&tile[(int)jv.x * BV]);
+          const V r1 = *reinterpret_cast<const V*>(&tile[(int)jv.y * BV]);
+          const V r2 = *reinterpret_cast<const V*>(&tile[(int)jv.z * BV]);
+          const V r3 = *reinterpret_cast<const V*>(&tile[(int)jv.w * BV]);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            acc[u][i] = fma(x.v[0], r0.v[i], acc[u][i]);
+            acc[u][i] = fma(x.v[1], r1.v[i], acc[u][i]);
+            acc[u][i] = fma(x.v[2], r2.v[i], acc[u][i]);
+            acc[u][i] = fma(x.v[3], r3.v[i], acc[u][i]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+#pragma unroll
+        for (int sft = 1; sft < GL; sft <<= 1)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[u][i] += __shfl_xor(acc[u][i], sft);
+        const int64_t m = mb + u * RPS + sub;
+        if (gl == 0 && m < a.M) {
+          if (a.P) {
+            T* p = a.P + ((int64_t)c * a.M + m) * BV;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) p[i] = acc[u][i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+              if (i < a.B) a.F[m * a.ldf + i] = acc[u][i];
+          }
+        }
+      }
+    }
+  } else {
+    // LPN lanes share a non-zero (each fetches VEC of the BV columns); a group of GL lanes shares a row
+    constexpr int RPS = 64 / GL;
+    constexpr int EPS = GL / LPN;  // entries per group step
+    const int sub = lane / GL, gl = lane % GL;
+    const int e0 = gl / LPN;
+    const int c0 = (gl % LPN) * VEC;
+    const int64_t stride = (int64_t)nslots * nwaves * RPS * UR;
+    for (int64_t mb = ((int64_t)slot * nwaves + wave) * RPS * UR; mb < a.M; mb += stride) {
+      int xb[UR], xe[UR];
+      int kk[UR];
+      T vv[UR];
+      T acc[UR][VEC];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int64_t m = mb + u * RPS + sub;
+        xb[u] = m < a.M ? off[m] * 4 : 0;
+        xe[u] = m < a.M ? off[m + 1] * 4 : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int x = xb[u] + e0;
+        const int xx = x < xe[u] ? x : xb[u];
+        kk[u] = a.idx[xx];
+        vv[u] = a.val[xx];
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[u][i] = T(0);
+        if (xb[u] + e0 < xe[u]) {
+          const V r = *reinterpret_cast<const V*>(&tile[kk[u] * BV + c0]);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[u][i] = fma(vv[u], r.v[i], acc[u][i]);
+        }
+        for (int x = xb[u] + e0 + EPS; x < xe[u]; x += EPS) {
+          const int k = a.idx[x];
+          const T v = a.val[x];
+          const V r = *reinterpret_cast<const V*>(&tile[k * BV + c0]);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[u][i] = fma(v, r.v[i], acc[u][i]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+#pragma unroll
+        for (int sft = LPN; sft < GL; sft <<= 1)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[u][i] += __shfl_xor(acc[u][i], sft);
+        const int64_t m = mb + u * RPS + sub;
+        if (e0 == 0 && m < a.M) {
+          if (a.P) {
+            T* p = a.P + ((int64_t)c * a.M + m) * BV + c0;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) p[i] = acc[u][i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+              if (c0 + i < a.B) a.F[m * a.ldf + c0 + i] = acc[u][i];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class T>
+__global__ void narrow_reduce_kernel(const T* __restrict__ P, int nchunks, int64_t M, int BV, int B, T* __restrict__ F,
+                                     int64_t ldf) {
+  const int64_t total = M * BV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / BV;
+    const int b = (int)(i - m * BV);
+    if (b >= B) continue;
+    T s = T(0);
+    for (int c = 0; c < nchunks; ++c) s += P[(int64_t)c * total + i];
+    F[m * ldf + b] = s;
+  }
+}
+
+template <class T>
+int narrow_chunk_cols(int bv) {
+  int64_t kc = (int64_t)(160 * 1024) / ((int64_t)bv * (int64_t)sizeof(T)) - 1;
+  if (kc > 65535) kc = 65535;
+  return (int)kc;
+}
+
+template <class T, int VEC, int LPN, int GL, int UR>
+static int launch_narrow_variant(const NarrowArgs<T>& a, unsigned grid, size_t lds) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR>), dim3(grid), dim3(NARROW_THREADS), lds,
+                     ctx().stream, a);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+template <class T, int VEC>
+static int launch_narrow_lpn1(const NarrowArgs<T>& a, unsigned grid, size_t lds, double mean_quads) {
+  constexpr int UR = VEC >= 8 ? 2 : 4;  // accumulators per lane = UR * VEC; stay inside 128 VGPRs
+  if (mean_quads > 40.0) return launch_narrow_variant<T, VEC, 1, 64, 2>(a, grid, lds);
+  if (mean_quads > 20.0) return launch_narrow_variant<T, VEC, 1, 32, UR>(a, grid, lds);
+  if (mean_quads > 10.0) return launch_narrow_variant<T, VEC, 1, 16, UR>(a, grid, lds);
+  return launch_narrow_variant<T, VEC, 1, 8, UR>(a, grid, lds);
+}
+
+// B = 8 / 16: group size so that a mean sub-row takes about two group steps
+template <class T, int LPN>
+static int launch_narrow_wide(const NarrowArgs<T>& a, unsigned grid, size_t lds, double mean_entries) {
+  const double steps64 = mean_entries / (64.0 / LPN);
+  if (steps64 > 2.0) return launch_narrow_variant<T, 4, LPN, 64, 2>(a, grid, lds);
+  if (steps64 > 1.0) return launch_narrow_variant<T, 4, LPN, 32, 4>(a, grid, lds);
+  return launch_narrow_variant<T, 4, LPN, 16, 4>(a, grid, lds);
+}
+
+template <class T>
+int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
+                               DevBuf<T>& partial) {
+  if (W.rows <= 0 || B <= 0) return SS_OK;
+  if (W.align != 4) return fail(SS_EINVAL, "narrow operand must be quad-aligned");
+  NarrowArgs<T> a{};
+  a.off = W.off.p; a.idx = W.idx.p; a.val = W.val.p;
+  a.M = W.rows; a.K = W.cols; a.KC = W.SC; a.nchunks = W.nchunks; a.B = B;
+  a.R = R; a.ldr = ldr; a.F = F; a.ldf = ldf; a.P = nullptr;
+  if (W.nchunks > 1) {
+    const size_t need = (size_t)W.nchunks * (size_t)W.rows * (size_t)bv;
+    if (partial.n < need) SS_TRY(partial.alloc(need));
+    a.P = partial.p;
+  }
+  // one resident round: the 160 KB tile allows one workgroup per CU, and every workgroup strides over
+  // all rows of its chunk, so a partial second round would only add idle CUs
+  int nslots = ctx().num_cu / W.nchunks;
+  const int64_t max_slots = ceil_div(W.rows, NARROW_THREADS / 64);
+  if (nslots > max_slots) nslots = (int)max_slots;
+  if (nslots < 1) nslots = 1;
+  const unsigned grid = (unsigned)(W.nchunks * nslots);
+  const size_t lds = (size_t)(W.SC + 1) * bv * sizeof(T);
+  const double mean_quads = (double)W.stored / 4.0 / ((double)W.rows * (double)W.nchunks);
+  int rc;
+  switch (bv) {
+    case 1: rc = launch_narrow_lpn1<T, 1>(a, grid, lds, mean_quads); break;
+    case 2: rc = launch_narrow_lpn1<T, 2>(a, grid, lds, mean_quads); break;
+    case 4: rc = launch_narrow_lpn1<T, 4>(a, grid, lds, mean_quads); break;
+    case 8: rc = launch_narrow_lpn1<T, 8>(a, grid, lds, mean_quads); break;
+    case 16: rc = getenv("SS_NARROW_LPN") ? launch_narrow_wide<T, 4>(a, grid, lds, mean_quads * 4.0)
+                                          : launch_narrow_lpn1<T, 16>(a, grid, lds, mean_quads); break;
+    default: return fail(SS_EINVAL, "narrow width must be 1, 2, 4, 8 or 16");
+  }
+  SS_TRY(rc);
+  if (W.nchunks > 1) {
+    hipLaunchKernelGGL(narrow_reduce_kernel<T>, dim3(grid_1d(W.rows * bv, 256)), dim3(256), 0, ctx().stream, partial.p,
+                       W.nchunks, W.rows, bv, B, F, ldf);
+    SS_LAUNCH_CHECK();
+  }
+  return SS_OK;
+}
+
 // ============================================================== transpose (layout conversion)
 // in: rows x cols, element (r,c) at in[r*ldin + c]; out: (c,r) at out[c*ldout + r]
 template <class T>
@@ -624,6 +907,9 @@ int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, i
   template int sell_max_chunk<T>(int);                                                                      \
   template int launch_spmm_sell<T>(const DevSell<T>&, const T*, int64_t, int64_t, T*, int64_t, const int*); \
   template int launch_spmm_csr_narrow<T>(const DevCsr<T>&, const T*, int64_t, int, T*, int64_t);            \
+  template int narrow_chunk_cols<T>(int);                                                                   \
+  template int launch_spmm_chunked_narrow<T>(const DevChunked<T>&, int, const T*, int64_t, int, T*, int64_t, \
+                                             DevBuf<T>&);                                                   \
   template int launch_transpose<T>(const T*, int64_t, int64_t, int64_t, T*, int64_t);                       \
   template int launch_loo_clean_fix<T>(const DevCsr<T>&, const int*, int64_t, int64_t, T*, int64_t);
 SS_INSTANTIATE(float)

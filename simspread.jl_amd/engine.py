@@ -24,7 +24,10 @@ def _suffix(dtype) -> str:
 
 
 def _is_torch(x) -> bool:
-    return type(x).__module__.startswith("torch")
+    if type(x).__module__.startswith("torch"):
+        L.use_torch_stream()  # order the library's kernels after the ones that produced this tensor
+        return True
+    return False
 
 
 def _csr_parts(m, dtype, shape=None):

@@ -348,8 +348,15 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
     W = sp.csr_matrix((rng.random(indptr[-1]) + 0.1, np.concatenate(rows), indptr), shape=(M, K))
     R = rng.random((K, 70))
     monkeypatch.setenv("SS_SELL_CHUNK", "1000")
+    monkeypatch.setenv("SS_NARROW_CHUNK", "700")
     w = ss.DeviceSpMat(W, dtype=np.float64)
     assert_close(w.spmm(R), W @ R, np.float64)
+    for B in (1, 2, 5, 16):       # LDS-chunked narrow kernel, 8 chunks, partial sums combined in order
+        assert_close(w.spmm(R[:, :B].copy()), W @ R[:, :B], np.float64)
+    w32 = ss.DeviceSpMat(W, dtype=np.float32)
+    for B in (1, 4, 9):
+        assert_close(w32.spmm(R[:, :B].astype(np.float32)), W @ R[:, :B], np.float32)
+    monkeypatch.setenv("SS_NARROW_CSR", "1")   # the L2-gather CSR kernel (what 16 < B <= 64 uses)
     assert_close(w.spmm(R[:, :5].copy()), W @ R[:, :5], np.float64)
 
 
