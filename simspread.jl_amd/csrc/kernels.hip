@@ -364,6 +364,7 @@ struct SellArgs {
 };
 
 constexpr int SELL_THREADS = 1024;
+constexpr int SELL_NB = 4;  // quads of W in flight per lane ahead of the gathers
 
 // Workgroup = QT columns of R (QT queries).  Per chunk of KC columns of W: the tile
 // R[b0..b0+QT)[k0..k0+KC) sits in LDS as [k][QT] so that one ds_read_b128 fetches the QT
@@ -391,6 +392,8 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
 
     const int* off = a.off + (int64_t)c * a.nslices;
     const bool last = (c == a.nchunks - 1);
+    const ushort4 pad4 = make_ushort4((unsigned short)a.KC, (unsigned short)a.KC, (unsigned short)a.KC,
+                                      (unsigned short)a.KC);
     for (int s = wave; s < a.nslices; s += nwaves) {
       const int o = __builtin_amdgcn_readfirstlane(off[s]);
       const int oe = __builtin_amdgcn_readfirstlane(off[s + 1]);
@@ -399,22 +402,51 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
       for (int q = 0; q < QT; ++q) acc[q] = T(0);
       const ushort4* ip = reinterpret_cast<const ushort4*>(a.idx) + (int64_t)o * 64 + lane;
       const Vec<T, 4>* vp = reinterpret_cast<const Vec<T, 4>*>(a.val) + (int64_t)o * 64 + lane;
-#pragma unroll 2
-      for (int u = o; u < oe; ++u, ip += 64, vp += 64) {
-        const ushort4 iv = *ip;
-        const V t0 = tile[iv.x], t1 = tile[iv.y], t2 = tile[iv.z], t3 = tile[iv.w];
-        if (BIN) {
+      // NB quads of indices (and values) are fetched ahead of the LDS gathers they feed: the index
+      // stream comes from L2 at several hundred cycles per access, the loop must not wait per quad
+      ushort4 iv[SELL_NB];
+      Vec<T, 4> wv[SELL_NB];
+      const int nq = oe - o;
+      const int qlast = nq > 0 ? nq - 1 : 0;  // loads are unconditional (clamped), the pad is a select:
+                                              // branches around loads make hipcc wait vmcnt(0) per batch
 #pragma unroll
-          for (int q = 0; q < QT; ++q) acc[q] += (t0.v[q] + t1.v[q]) + (t2.v[q] + t3.v[q]);
-        } else {
-          const Vec<T, 4> w = *vp;
+      for (int j = 0; j < SELL_NB; ++j) {
+        const int xc = j < qlast ? j : qlast;
+        const ushort4 li = ip[(int64_t)xc * 64];
+        iv[j] = j < nq ? li : pad4;
+        if (!BIN) wv[j] = vp[(int64_t)xc * 64];  // a padded index reads the zero tile row: any weight is fine
+      }
+      for (int u = 0; u < nq; u += SELL_NB) {
+        ushort4 in[SELL_NB];
+        Vec<T, 4> wn[SELL_NB];
 #pragma unroll
-          for (int q = 0; q < QT; ++q) {
-            acc[q] = fma(w.v[0], t0.v[q], acc[q]);
-            acc[q] = fma(w.v[1], t1.v[q], acc[q]);
-            acc[q] = fma(w.v[2], t2.v[q], acc[q]);
-            acc[q] = fma(w.v[3], t3.v[q], acc[q]);
+        for (int j = 0; j < SELL_NB; ++j) {
+          const int x = u + SELL_NB + j;
+          const int xc = x < qlast ? x : qlast;
+          const ushort4 li = ip[(int64_t)xc * 64];
+          in[j] = x < nq ? li : pad4;
+          if (!BIN) wn[j] = vp[(int64_t)xc * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < SELL_NB; ++j) {
+          const V t0 = tile[iv[j].x], t1 = tile[iv[j].y], t2 = tile[iv[j].z], t3 = tile[iv[j].w];
+          if (BIN) {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) acc[q] += (t0.v[q] + t1.v[q]) + (t2.v[q] + t3.v[q]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+              acc[q] = fma(wv[j].v[0], t0.v[q], acc[q]);
+              acc[q] = fma(wv[j].v[1], t1.v[q], acc[q]);
+              acc[q] = fma(wv[j].v[2], t2.v[q], acc[q]);
+              acc[q] = fma(wv[j].v[3], t3.v[q], acc[q]);
+            }
           }
+        }
+#pragma unroll
+        for (int j = 0; j < SELL_NB; ++j) {
+          iv[j] = in[j];
+          if (!BIN) wv[j] = wn[j];
         }
       }
       const int64_t m = (int64_t)s * 64 + lane;
