@@ -369,8 +369,23 @@ constexpr int SELL_NB = 4;  // quads of W in flight per lane ahead of the gather
 // Workgroup = QT columns of R (QT queries).  Per chunk of KC columns of W: the tile
 // R[b0..b0+QT)[k0..k0+KC) sits in LDS as [k][QT] so that one ds_read_b128 fetches the QT
 // operands of a non-zero; waves walk the slices, lane = row of W, no cross-lane reduction.
+// (16-bit half H of x) << sh in one VALU instruction (SDWA source select)
+template <int H>
+__device__ __forceinline__ unsigned half_shl(unsigned x, unsigned sh) {
+  unsigned r;
+  if (H == 0)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(r) : "v"(sh), "v"(x));
+  else
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(r) : "v"(sh), "v"(x));
+  return r;
+}
+
 template <class T, int QT, bool BIN>
 __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) {
+  constexpr unsigned TSH = 4;  // log2(sizeof(Vec<T,QT>)): 16-byte tile rows for (float,4) and (double,2)
+  static_assert(sizeof(Vec<T, QT>) == 16, "tile row must be 16 bytes");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   using V = Vec<T, QT>;
   V* tile = reinterpret_cast<V*>(smem_raw);  // [KC + 1]; entry KC stays zero (padding target)
@@ -392,8 +407,6 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
 
     const int* off = a.off + (int64_t)c * a.nslices;
     const bool last = (c == a.nchunks - 1);
-    const ushort4 pad4 = make_ushort4((unsigned short)a.KC, (unsigned short)a.KC, (unsigned short)a.KC,
-                                      (unsigned short)a.KC);
     for (int s = wave; s < a.nslices; s += nwaves) {
       const int o = __builtin_amdgcn_readfirstlane(off[s]);
       const int oe = __builtin_amdgcn_readfirstlane(off[s + 1]);
@@ -403,50 +416,56 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
       const ushort4* ip = reinterpret_cast<const ushort4*>(a.idx) + (int64_t)o * 64 + lane;
       const Vec<T, 4>* vp = reinterpret_cast<const Vec<T, 4>*>(a.val) + (int64_t)o * 64 + lane;
       // NB quads of indices (and values) are fetched ahead of the LDS gathers they feed: the index
-      // stream comes from L2 at several hundred cycles per access, the loop must not wait per quad
-      ushort4 iv[SELL_NB];
-      Vec<T, 4> wv[SELL_NB];
+      // stream comes from L2 at several hundred cycles per access, the loop must not wait per quad.
+      // Loads are unconditional (clamped) and the pad is a select: branches around loads make hipcc
+      // wait vmcnt(0) per batch.  Two register sets (A/B) alternate so that nothing is copied.
+      const uint2* ipw = reinterpret_cast<const uint2*>(ip);
       const int nq = oe - o;
-      const int qlast = nq > 0 ? nq - 1 : 0;  // loads are unconditional (clamped), the pad is a select:
-                                              // branches around loads make hipcc wait vmcnt(0) per batch
-#pragma unroll
-      for (int j = 0; j < SELL_NB; ++j) {
-        const int xc = j < qlast ? j : qlast;
-        const ushort4 li = ip[(int64_t)xc * 64];
-        iv[j] = j < nq ? li : pad4;
-        if (!BIN) wv[j] = vp[(int64_t)xc * 64];  // a padded index reads the zero tile row: any weight is fine
-      }
-      for (int u = 0; u < nq; u += SELL_NB) {
-        ushort4 in[SELL_NB];
-        Vec<T, 4> wn[SELL_NB];
+      const int qlast = nq > 0 ? nq - 1 : 0;
+      const uint2 padw = make_uint2(((unsigned)a.KC << 16) | (unsigned)a.KC, ((unsigned)a.KC << 16) | (unsigned)a.KC);
+      uint2 ia[SELL_NB], ib[SELL_NB];
+      Vec<T, 4> wa[SELL_NB], wb[SELL_NB];
+      auto fetch = [&](uint2 (&iq)[SELL_NB], Vec<T, 4> (&wq)[SELL_NB], int base) {
 #pragma unroll
         for (int j = 0; j < SELL_NB; ++j) {
-          const int x = u + SELL_NB + j;
+          const int x = base + j;
           const int xc = x < qlast ? x : qlast;
-          const ushort4 li = ip[(int64_t)xc * 64];
-          in[j] = x < nq ? li : pad4;
-          if (!BIN) wn[j] = vp[(int64_t)xc * 64];
+          const uint2 li = ipw[(int64_t)xc * 64];
+          iq[j].x = x < nq ? li.x : padw.x;
+          iq[j].y = x < nq ? li.y : padw.y;
+          if (!BIN) wq[j] = vp[(int64_t)xc * 64];  // a padded index reads the zero tile row: any weight is fine
         }
+      };
+      auto gather = [&](const uint2 (&iq)[SELL_NB], const Vec<T, 4> (&wq)[SELL_NB]) {
+        const char* tb = reinterpret_cast<const char*>(tile);
 #pragma unroll
         for (int j = 0; j < SELL_NB; ++j) {
-          const V t0 = tile[iv[j].x], t1 = tile[iv[j].y], t2 = tile[iv[j].z], t3 = tile[iv[j].w];
+          // byte offset of tile[k] = k * 16: one SDWA shift per 16-bit index
+          const V t0 = *reinterpret_cast<const V*>(tb + half_shl<0>(iq[j].x, TSH));
+          const V t1 = *reinterpret_cast<const V*>(tb + half_shl<1>(iq[j].x, TSH));
+          const V t2 = *reinterpret_cast<const V*>(tb + half_shl<0>(iq[j].y, TSH));
+          const V t3 = *reinterpret_cast<const V*>(tb + half_shl<1>(iq[j].y, TSH));
           if (BIN) {
 #pragma unroll
             for (int q = 0; q < QT; ++q) acc[q] += (t0.v[q] + t1.v[q]) + (t2.v[q] + t3.v[q]);
           } else {
 #pragma unroll
             for (int q = 0; q < QT; ++q) {
-              acc[q] = fma(wv[j].v[0], t0.v[q], acc[q]);
-              acc[q] = fma(wv[j].v[1], t1.v[q], acc[q]);
-              acc[q] = fma(wv[j].v[2], t2.v[q], acc[q]);
-              acc[q] = fma(wv[j].v[3], t3.v[q], acc[q]);
+              acc[q] = fma(wq[j].v[0], t0.v[q], acc[q]);
+              acc[q] = fma(wq[j].v[1], t1.v[q], acc[q]);
+              acc[q] = fma(wq[j].v[2], t2.v[q], acc[q]);
+              acc[q] = fma(wq[j].v[3], t3.v[q], acc[q]);
             }
           }
         }
-#pragma unroll
-        for (int j = 0; j < SELL_NB; ++j) {
-          iv[j] = in[j];
-          if (!BIN) wv[j] = wn[j];
+      };
+      fetch(ia, wa, 0);
+      for (int u = 0; u < nq; u += 2 * SELL_NB) {
+        fetch(ib, wb, u + SELL_NB);
+        gather(ia, wa);
+        if (u + SELL_NB < nq) {
+          fetch(ia, wa, u + 2 * SELL_NB);
+          gather(ib, wb);
         }
       }
       const int64_t m = (int64_t)s * 64 + lane;
