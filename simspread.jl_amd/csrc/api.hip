@@ -281,12 +281,14 @@ static int graph_chunked(Graph<T>& g, bool need_y) {
     const int64_t ns = g.ns > 0 ? g.ns : 1;
     const double mean_len = g.XsT.rows > 0 ? (double)g.XsT.nnz / (double)g.XsT.rows : 0.0;
     int64_t sc = mean_len > 1.0 ? (int64_t)(64.0 * (double)ns / mean_len) : ns;
-    const int64_t sc_max = sizeof(T) == 4 ? 8192 : 4096;
+    // keep >= 8 single-wave workgroups per CU: (SC + 64) * sizeof(T) <= 20 KiB (measured at 100k x 100k, 1 %:
+    // SC 6250 -> 7.7 ms, 4167 -> 4.5 ms, 3200 -> 5.9 ms for 2048 folds)
+    const int64_t sc_max = (20 * 1024) / (int64_t)sizeof(T) - 64;
     if (sc > sc_max) sc = sc_max;
     if (sc < 256) sc = 256;
     if (const char* e = getenv("SS_TRANSFER_CHUNK")) {
       const long long v = atoll(e);
-      if (v >= 16 && v <= 16384) sc = v;
+      if (v >= 16 && v <= 8192) sc = v;
     }
     int64_t nch = ceil_div(ns, sc);
     if (nch > 1) nch = ceil_div(nch, 8) * 8;
@@ -343,10 +345,21 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
       }
       timing_count(ST_NTRANSFER, 1);
     }
-    {
+    if (!g.W.sorted) {
       StageTimer t2(ST_SPMM);
       SS_TRY(launch_spmm_sell<T>(g.W, Tbuf.p, nj, nb, dev_out + r0 * ldo, ldo, clean ? g.kt.p : nullptr));
       timing_count(ST_NSPMM, 1);
+    } else {
+      // skew-sorted operand: scores come out in sorted target order, then go back through inv[] (+ clean!)
+      const size_t need_s = (size_t)rb * (size_t)g.nt;
+      if (g.Sws.n < need_s) SS_TRY(g.Sws.alloc(need_s));
+      {
+        StageTimer t2(ST_SPMM);
+        SS_TRY(launch_spmm_sell<T>(g.W, Tbuf.p, nj, nb, g.Sws.p, g.nt, nullptr));
+        timing_count(ST_NSPMM, 1);
+      }
+      StageTimer t3(ST_EPILOGUE);
+      SS_TRY(launch_unpermute<T>(g.Sws.p, g.nt, nb, g.nt, g.W.inv.p, clean ? g.kt.p : nullptr, dev_out + r0 * ldo, ldo));
     }
   }
   if (kind == 2 && clean) {
@@ -546,10 +559,20 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
       Fc = Ft.p;
       ldfc = M;
     }
-    {
+    DevBuf<T> Fs;  // skew-sorted operand: sorted-order result, put back through inv[]
+    if (!m.sell.sorted) {
       StageTimer t2(ST_SPMM);
       SS_TRY(launch_spmm_sell<T>(m.sell, Rc, ldrc, B, Fc, ldfc, nullptr));
       timing_count(ST_NSPMM, 1);
+    } else {
+      SS_TRY(Fs.alloc((size_t)B * M));
+      {
+        StageTimer t2(ST_SPMM);
+        SS_TRY(launch_spmm_sell<T>(m.sell, Rc, ldrc, B, Fs.p, M, nullptr));
+        timing_count(ST_NSPMM, 1);
+      }
+      StageTimer t3(ST_EPILOGUE);
+      SS_TRY(launch_unpermute<T>(Fs.p, M, B, M, m.sell.inv.p, nullptr, Fc, ldfc));
     }
     if (f_layout == SS_LAYOUT_ROWMAJOR) {
       StageTimer t3(ST_EPILOGUE);

@@ -401,14 +401,16 @@ int csr_transpose(const DevCsr<T>& in, DevCsr<T>& out) {
 // ------------------------------------------------------------------ CSR -> chunked SELL-64 with 16-bit local indices
 // one wave per (chunk, slice): lane = row; width = max entries of the 64 rows inside the chunk, in quads
 __global__ void sell_width_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, int64_t rows, int KC,
-                                  int nslices, int nchunks, int* __restrict__ widthq) {
+                                  int nslices, int nchunks, const int* __restrict__ perm,
+                                  int* __restrict__ widthq) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= (int64_t)nslices * nchunks) return;
   const int c = (int)(wave / nslices), s = (int)(wave % nslices);
-  const int64_t r = (int64_t)s * 64 + lane;
+  const int64_t pos = (int64_t)s * 64 + lane;
+  const int64_t r = (pos < rows && perm) ? perm[pos] : pos;
   int n = 0;
-  if (r < rows) {
+  if (pos < rows) {
     int lo = ptr[r], hi = ptr[r + 1];
     const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
     int a = lo, b = hi;
@@ -425,15 +427,17 @@ __global__ void sell_width_kernel(const int* __restrict__ ptr, const int* __rest
 template <class T>
 __global__ void sell_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
                                  int64_t rows, int KC, int nslices, int nchunks, const int* __restrict__ off,
-                                 unsigned short* __restrict__ sidx, T* __restrict__ sval) {
+                                 const int* __restrict__ perm, unsigned short* __restrict__ sidx,
+                                 T* __restrict__ sval) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= (int64_t)nslices * nchunks) return;
   const int c = (int)(wave / nslices), s = (int)(wave % nslices);
-  const int64_t r = (int64_t)s * 64 + lane;
+  const int64_t pos = (int64_t)s * 64 + lane;
+  const int64_t r = (pos < rows && perm) ? perm[pos] : pos;
   int first = 0, n = 0;
   const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
-  if (r < rows) {
+  if (pos < rows) {
     int lo = ptr[r], hi = ptr[r + 1];
     int a = lo, b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
@@ -486,6 +490,7 @@ template <class T>
 __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
                                                              const T* __restrict__ val, int64_t rows, int KC,
                                                              int nslices, int nchunks, const int* __restrict__ off,
+                                                             const int* __restrict__ rowperm,
                                                              int* __restrict__ perm, unsigned short* __restrict__ sidx,
                                                              T* __restrict__ sval) {
   __shared__ unsigned short cnt[64][17];
@@ -493,10 +498,11 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
   const int lane = threadIdx.x;
   const int64_t wave = blockIdx.x;
   const int c = (int)(wave / nslices), s = (int)(wave % nslices);
-  const int64_t r = (int64_t)s * 64 + lane;
+  const int64_t pos = (int64_t)s * 64 + lane;
+  const int64_t r = (pos < rows && rowperm) ? rowperm[pos] : pos;
   int first = 0, n = 0;
   const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
-  if (r < rows) {
+  if (pos < rows) {
     int lo = ptr[r], hi = ptr[r + 1];
     int a = lo, b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
@@ -558,6 +564,18 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
   }
 }
 
+__global__ void row_len_iota_kernel(const int* __restrict__ ptr, int64_t rows, int* __restrict__ len,
+                                    int* __restrict__ iota) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+    len[i] = ptr[i + 1] - ptr[i];
+    iota[i] = (int)i;
+  }
+}
+__global__ void invert_perm_kernel(const int* __restrict__ perm, int64_t rows, int* __restrict__ inv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x)
+    inv[perm[i]] = (int)i;
+}
+
 template <class T>
 int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   hipStream_t st = ctx().stream;
@@ -579,12 +597,44 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   }
   DevBuf<int> widthq;
   SS_TRY(widthq.alloc(nws));
+  out.sorted = false;
   hipLaunchKernelGGL(sell_width_kernel, dim3((unsigned)ceil_div(nws * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p,
-                     in.rows, out.KC, out.nslices, out.nchunks, widthq.p);
+                     in.rows, out.KC, out.nslices, out.nchunks, (const int*)nullptr, widthq.p);
   SS_LAUNCH_CHECK();
   SS_TRY(exclusive_scan_int(widthq.p, out.off.p, nws));
   int nq = 0;
   SS_TRY(read_int(out.off.p + nws, &nq));
+  // padded storage well above nnz means skewed row lengths inside slices: sort the rows by length first
+  const char* force = getenv("SS_SELL_SORT");
+  const bool want_sort = force ? atoi(force) != 0 : ((double)nq * 256.0 > 1.3 * (double)in.nnz + 65536.0);
+  if (want_sort && in.rows > 64) {
+    DevBuf<int> len, len_sorted, iota;
+    SS_TRY(len.alloc(in.rows));
+    SS_TRY(len_sorted.alloc(in.rows));
+    SS_TRY(iota.alloc(in.rows));
+    SS_TRY(out.perm.alloc(in.rows));
+    SS_TRY(out.inv.alloc(in.rows));
+    hipLaunchKernelGGL(row_len_iota_kernel, dim3(grid_for(in.rows, 256)), dim3(256), 0, st, in.ptr.p, in.rows, len.p,
+                       iota.p);
+    SS_LAUNCH_CHECK();
+    size_t bytes = 0;
+    SS_HIP(rocprim::radix_sort_pairs_desc(nullptr, bytes, len.p, len_sorted.p, iota.p, out.perm.p, (size_t)in.rows, 0u,
+                                          32u, st));
+    DevBuf<unsigned char> tmp;
+    SS_TRY(tmp.alloc(bytes));
+    SS_HIP(rocprim::radix_sort_pairs_desc(tmp.p, bytes, len.p, len_sorted.p, iota.p, out.perm.p, (size_t)in.rows, 0u,
+                                          32u, st));
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(grid_for(in.rows, 256)), dim3(256), 0, st, out.perm.p, in.rows,
+                       out.inv.p);
+    SS_LAUNCH_CHECK();
+    out.sorted = true;
+    hipLaunchKernelGGL(sell_width_kernel, dim3((unsigned)ceil_div(nws * 64, 256)), dim3(256), 0, st, in.ptr.p,
+                       in.idx.p, in.rows, out.KC, out.nslices, out.nchunks, (const int*)out.perm.p, widthq.p);
+    SS_LAUNCH_CHECK();
+    SS_TRY(exclusive_scan_int(widthq.p, out.off.p, nws));
+    SS_TRY(read_int(out.off.p + nws, &nq));
+    SS_HIP(hipStreamSynchronize(st));
+  }
   if (nq < 0 || (int64_t)nq * 256 >= (1LL << 40)) return fail(SS_EUNSUPPORTED, "SELL storage too large");
   out.nquads = nq;
   SS_TRY(out.idx.alloc((size_t)nq * 256));
@@ -592,14 +642,16 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   else out.val.release();
   if (getenv("SS_SELL_PLAIN")) {
     hipLaunchKernelGGL(sell_fill_kernel<T>, dim3((unsigned)ceil_div(nws * 64, 256)), dim3(256), 0, st, in.ptr.p,
-                       in.idx.p, in.val.p, in.rows, out.KC, out.nslices, out.nchunks, out.off.p, out.idx.p,
+                       in.idx.p, in.val.p, in.rows, out.KC, out.nslices, out.nchunks, out.off.p,
+                       out.sorted ? (const int*)out.perm.p : (const int*)nullptr, out.idx.p,
                        out.binary ? (T*)nullptr : out.val.p);
     SS_LAUNCH_CHECK();
   } else {
     DevBuf<int> perm;
     SS_TRY(perm.alloc(in.nnz));
     hipLaunchKernelGGL(sell_fill_sched_kernel<T>, dim3((unsigned)nws), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p,
-                       in.rows, out.KC, out.nslices, out.nchunks, out.off.p, perm.p, out.idx.p,
+                       in.rows, out.KC, out.nslices, out.nchunks, out.off.p,
+                       out.sorted ? (const int*)out.perm.p : (const int*)nullptr, perm.p, out.idx.p,
                        out.binary ? (T*)nullptr : out.val.p);
     SS_LAUNCH_CHECK();
     SS_HIP(hipStreamSynchronize(st));

@@ -31,6 +31,11 @@ struct DevSell {
   DevBuf<int> off;              // [nchunks*nslices + 1] quad offsets, chunk-major
   DevBuf<unsigned short> idx;   // [nquads][64][4]
   DevBuf<T> val;                // [nquads][64][4] unless binary
+  // skewed row lengths (power-law graphs): rows are sorted by length before they are cut into slices so
+  // that the 64 rows of a slice are equally long; results then come out in sorted order and are put back
+  // by unpermute_kernel.  perm[sorted position] = row, inv[row] = sorted position.
+  bool sorted = false;
+  DevBuf<int> perm, inv;
 };
 
 // CSR cut into column chunks of SC columns, stored chunk-major with chunk-local 16-bit indices:
@@ -65,6 +70,7 @@ struct Graph {
   int W_qt = 0;
   DevChunked<T> XsTc, YsTc;  // stage-1 operands (YsTc only for source rows), built lazily
   DevBuf<T> Tws;  // workspace: rows of the transfer block T between stage 1 and stage 2
+  DevBuf<T> Sws;  // workspace: sorted-order scores of a skew-sorted stage-2 operand
 };
 
 template <class T>
@@ -141,6 +147,10 @@ int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T
 
 template <class T>
 int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout);
+// out[r][t] = clean(in[r][inv[t]]): undo the row sort of a skew-sorted SELL operand (+ fused clean!)
+template <class T>
+int launch_unpermute(const T* in, int64_t ldin, int64_t nrows, int64_t nt, const int* inv, const int* clean_deg,
+                     T* out, int64_t ldout);
 // clean! for leave-one-out rows: target t whose only edge belongs to query i
 template <class T>
 int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, int64_t nrows, T* out, int64_t ld);

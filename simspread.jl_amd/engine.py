@@ -88,6 +88,34 @@ class DeviceGraph:
         return cls(h, dtype)
 
     @classmethod
+    def from_device_csr(cls, nq, ns, nf, nt, xq, xs, ys, dtype=np.float32):
+        """CSR blocks that already live on the GPU: each of xq, xs, ys is a (ptr int64, idx int32, val)
+        triple of torch CUDA tensors (xq may be None; a val of None means all ones)."""
+        lib = L.lib()
+        import torch
+
+        def parts(t, rows):
+            if t is None:
+                z = torch.zeros(rows + 1, dtype=torch.int64, device="cuda")
+                return z, None, None, (z,)
+            ptr, idx, val = t
+            _is_torch(ptr)
+            want = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+            if ptr.dtype != torch.int64 or idx.dtype != torch.int32 or (val is not None and val.dtype != want):
+                raise TypeError("device CSR needs int64 pointers, int32 indices and values of the graph precision")
+            return ptr, idx, val, (ptr, idx, val)
+
+        dp = lambda t: None if t is None else t.data_ptr()
+        q = parts(xq, nq)
+        s_ = parts(xs, ns)
+        y = parts(ys, ns)
+        h = C.c_void_p()
+        fn = getattr(lib, f"ss_graph_create_csr_{_suffix(dtype)}")
+        L.check(fn(nq, ns, nf, nt, dp(q[0]), dp(q[1]), dp(q[2]), dp(s_[0]), dp(s_[1]), dp(s_[2]),
+                   dp(y[0]), dp(y[1]), dp(y[2]), 0, L.SS_MEM_DEVICE, C.byref(h)))
+        return cls(h, dtype)
+
+    @classmethod
     def from_dense(cls, Sq, Ss, Y, alpha: Optional[float] = None, weighted: bool = True, dtype=np.float32):
         """Dense blocks; with ``alpha`` the featurize cutoff (src/core.jl:106-112) is applied on the
         device while the CSR operands are assembled.  Arrays may be numpy (any order) or torch CUDA
