@@ -351,15 +351,16 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
       timing_count(ST_NSPMM, 1);
     } else {
       // skew-sorted operand: scores come out in sorted target order, then go back through inv[] (+ clean!)
-      const size_t need_s = (size_t)rb * (size_t)g.nt;
+      const size_t need_s = (size_t)rb * (size_t)g.W.vrows;
       if (g.Sws.n < need_s) SS_TRY(g.Sws.alloc(need_s));
       {
         StageTimer t2(ST_SPMM);
-        SS_TRY(launch_spmm_sell<T>(g.W, Tbuf.p, nj, nb, g.Sws.p, g.nt, nullptr));
+        SS_TRY(launch_spmm_sell<T>(g.W, Tbuf.p, nj, nb, g.Sws.p, g.W.vrows, nullptr));
         timing_count(ST_NSPMM, 1);
       }
       StageTimer t3(ST_EPILOGUE);
-      SS_TRY(launch_unpermute<T>(g.Sws.p, g.nt, nb, g.nt, g.W.inv.p, clean ? g.kt.p : nullptr, dev_out + r0 * ldo, ldo));
+      SS_TRY(launch_unpermute<T>(g.Sws.p, g.W.vrows, nb, g.nt, g.W.vfirst.p, g.W.inv.p, clean ? g.kt.p : nullptr,
+                                 dev_out + r0 * ldo, ldo));
     }
   }
   if (kind == 2 && clean) {
@@ -565,14 +566,14 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
       SS_TRY(launch_spmm_sell<T>(m.sell, Rc, ldrc, B, Fc, ldfc, nullptr));
       timing_count(ST_NSPMM, 1);
     } else {
-      SS_TRY(Fs.alloc((size_t)B * M));
+      SS_TRY(Fs.alloc((size_t)B * m.sell.vrows));
       {
         StageTimer t2(ST_SPMM);
-        SS_TRY(launch_spmm_sell<T>(m.sell, Rc, ldrc, B, Fs.p, M, nullptr));
+        SS_TRY(launch_spmm_sell<T>(m.sell, Rc, ldrc, B, Fs.p, m.sell.vrows, nullptr));
         timing_count(ST_NSPMM, 1);
       }
       StageTimer t3(ST_EPILOGUE);
-      SS_TRY(launch_unpermute<T>(Fs.p, M, B, M, m.sell.inv.p, nullptr, Fc, ldfc));
+      SS_TRY(launch_unpermute<T>(Fs.p, m.sell.vrows, B, M, m.sell.vfirst.p, m.sell.inv.p, nullptr, Fc, ldfc));
     }
     if (f_layout == SS_LAYOUT_ROWMAJOR) {
       StageTimer t3(ST_EPILOGUE);

@@ -401,17 +401,16 @@ int csr_transpose(const DevCsr<T>& in, DevCsr<T>& out) {
 // ------------------------------------------------------------------ CSR -> chunked SELL-64 with 16-bit local indices
 // one wave per (chunk, slice): lane = row; width = max entries of the 64 rows inside the chunk, in quads
 __global__ void sell_width_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, int64_t rows, int KC,
-                                  int nslices, int nchunks, const int* __restrict__ perm,
+                                  int nslices, int nchunks, const int* __restrict__ vs, const int* __restrict__ ve,
                                   int* __restrict__ widthq) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= (int64_t)nslices * nchunks) return;
   const int c = (int)(wave / nslices), s = (int)(wave % nslices);
-  const int64_t pos = (int64_t)s * 64 + lane;
-  const int64_t r = (pos < rows && perm) ? perm[pos] : pos;
+  const int64_t pos = (int64_t)s * 64 + lane;  // `rows` counts virtual rows when vs/ve are given
   int n = 0;
   if (pos < rows) {
-    int lo = ptr[r], hi = ptr[r + 1];
+    int lo = vs ? vs[pos] : ptr[pos], hi = ve ? ve[pos] : ptr[pos + 1];
     const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
     int a = lo, b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
@@ -427,18 +426,17 @@ __global__ void sell_width_kernel(const int* __restrict__ ptr, const int* __rest
 template <class T>
 __global__ void sell_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
                                  int64_t rows, int KC, int nslices, int nchunks, const int* __restrict__ off,
-                                 const int* __restrict__ perm, unsigned short* __restrict__ sidx,
-                                 T* __restrict__ sval) {
+                                 const int* __restrict__ vs, const int* __restrict__ ve,
+                                 unsigned short* __restrict__ sidx, T* __restrict__ sval) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= (int64_t)nslices * nchunks) return;
   const int c = (int)(wave / nslices), s = (int)(wave % nslices);
   const int64_t pos = (int64_t)s * 64 + lane;
-  const int64_t r = (pos < rows && perm) ? perm[pos] : pos;
   int first = 0, n = 0;
   const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
   if (pos < rows) {
-    int lo = ptr[r], hi = ptr[r + 1];
+    int lo = vs ? vs[pos] : ptr[pos], hi = ve ? ve[pos] : ptr[pos + 1];
     int a = lo, b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
     first = a;
@@ -490,7 +488,7 @@ template <class T>
 __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
                                                              const T* __restrict__ val, int64_t rows, int KC,
                                                              int nslices, int nchunks, const int* __restrict__ off,
-                                                             const int* __restrict__ rowperm,
+                                                             const int* __restrict__ vs, const int* __restrict__ ve,
                                                              int* __restrict__ perm, unsigned short* __restrict__ sidx,
                                                              T* __restrict__ sval) {
   __shared__ unsigned short cnt[64][17];
@@ -499,11 +497,10 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
   const int64_t wave = blockIdx.x;
   const int c = (int)(wave / nslices), s = (int)(wave % nslices);
   const int64_t pos = (int64_t)s * 64 + lane;
-  const int64_t r = (pos < rows && rowperm) ? rowperm[pos] : pos;
   int first = 0, n = 0;
   const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
   if (pos < rows) {
-    int lo = ptr[r], hi = ptr[r + 1];
+    int lo = vs ? vs[pos] : ptr[pos], hi = ve ? ve[pos] : ptr[pos + 1];
     int a = lo, b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
     first = a;
@@ -564,16 +561,36 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
   }
 }
 
-__global__ void row_len_iota_kernel(const int* __restrict__ ptr, int64_t rows, int* __restrict__ len,
-                                    int* __restrict__ iota) {
+__global__ void vrow_parts_kernel(const int* __restrict__ ptr, int64_t rows, int lmax, int* __restrict__ nparts) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
-    len[i] = ptr[i + 1] - ptr[i];
-    iota[i] = (int)i;
+    const int len = ptr[i + 1] - ptr[i];
+    nparts[i] = len > lmax ? (len + lmax - 1) / lmax : 1;
   }
 }
-__global__ void invert_perm_kernel(const int* __restrict__ perm, int64_t rows, int* __restrict__ inv) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x)
-    inv[perm[i]] = (int)i;
+// virtual row v = part p of real row r: entries [ptr[r] + p*lmax, min(ptr[r+1], ...+lmax))
+__global__ void vrow_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ vfirst, int64_t rows, int lmax,
+                                 int* __restrict__ vstart, int* __restrict__ vlen, int* __restrict__ iota) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int lo = ptr[r], hi = ptr[r + 1];
+    for (int v = vfirst[r], p = 0; v < vfirst[r + 1]; ++v, ++p) {
+      const int b = lo + p * lmax;
+      const int e = (b + lmax < hi) ? b + lmax : hi;
+      vstart[v] = b;
+      vlen[v] = e > b ? e - b : 0;
+      iota[v] = v;
+    }
+  }
+}
+// perm[pos] = virtual id (sorted by length, descending): ranges by position and the inverse map
+__global__ void vrow_place_kernel(const int* __restrict__ perm, const int* __restrict__ vstart,
+                                  const int* __restrict__ vlen, int64_t n, int* __restrict__ vs, int* __restrict__ ve,
+                                  int* __restrict__ inv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = perm[i];
+    vs[i] = vstart[v];
+    ve[i] = vstart[v] + vlen[v];
+    inv[v] = (int)i;
+  }
 }
 
 template <class T>
@@ -599,59 +616,84 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   SS_TRY(widthq.alloc(nws));
   out.sorted = false;
   hipLaunchKernelGGL(sell_width_kernel, dim3((unsigned)ceil_div(nws * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p,
-                     in.rows, out.KC, out.nslices, out.nchunks, (const int*)nullptr, widthq.p);
+                     in.rows, out.KC, out.nslices, out.nchunks, (const int*)nullptr, (const int*)nullptr, widthq.p);
   SS_LAUNCH_CHECK();
   SS_TRY(exclusive_scan_int(widthq.p, out.off.p, nws));
   int nq = 0;
   SS_TRY(read_int(out.off.p + nws, &nq));
-  // padded storage well above nnz means skewed row lengths inside slices: sort the rows by length first
+  out.vrows = in.rows;
+  // padded storage well above nnz means skewed row lengths inside slices: split the longest rows into
+  // virtual rows of bounded length and sort all (virtual) rows by length before cutting slices
   const char* force = getenv("SS_SELL_SORT");
   const bool want_sort = force ? atoi(force) != 0 : ((double)nq * 256.0 > 1.3 * (double)in.nnz + 65536.0);
   if (want_sort && in.rows > 64) {
-    DevBuf<int> len, len_sorted, iota;
-    SS_TRY(len.alloc(in.rows));
-    SS_TRY(len_sorted.alloc(in.rows));
-    SS_TRY(iota.alloc(in.rows));
-    SS_TRY(out.perm.alloc(in.rows));
-    SS_TRY(out.inv.alloc(in.rows));
-    hipLaunchKernelGGL(row_len_iota_kernel, dim3(grid_for(in.rows, 256)), dim3(256), 0, st, in.ptr.p, in.rows, len.p,
-                       iota.p);
+    int64_t lmax = in.nnz / 4096;  // a slice of full-length virtual rows is ~1/4 of one wave's share of a workgroup
+    if (const char* e = getenv("SS_SELL_LMAX")) lmax = atoll(e);
+    if (lmax < 256) lmax = 256;
+    if (lmax > 65536) lmax = 65536;
+    lmax &= ~3LL;
+    DevBuf<int> nparts, vstart, vlen, vlen_sorted, iota, perm;
+    SS_TRY(nparts.alloc(in.rows));
+    SS_TRY(out.vfirst.alloc(in.rows + 1));
+    hipLaunchKernelGGL(vrow_parts_kernel, dim3(grid_for(in.rows, 256)), dim3(256), 0, st, in.ptr.p, in.rows, (int)lmax,
+                       nparts.p);
+    SS_LAUNCH_CHECK();
+    SS_TRY(exclusive_scan_int(nparts.p, out.vfirst.p, in.rows));
+    int nv = 0;
+    SS_TRY(read_int(out.vfirst.p + in.rows, &nv));
+    out.vrows = nv;
+    SS_TRY(vstart.alloc(nv));
+    SS_TRY(vlen.alloc(nv));
+    SS_TRY(vlen_sorted.alloc(nv));
+    SS_TRY(iota.alloc(nv));
+    SS_TRY(perm.alloc(nv));
+    SS_TRY(out.vs.alloc(nv));
+    SS_TRY(out.ve.alloc(nv));
+    SS_TRY(out.inv.alloc(nv));
+    hipLaunchKernelGGL(vrow_fill_kernel, dim3(grid_for(in.rows, 256)), dim3(256), 0, st, in.ptr.p, out.vfirst.p, in.rows,
+                       (int)lmax, vstart.p, vlen.p, iota.p);
     SS_LAUNCH_CHECK();
     size_t bytes = 0;
-    SS_HIP(rocprim::radix_sort_pairs_desc(nullptr, bytes, len.p, len_sorted.p, iota.p, out.perm.p, (size_t)in.rows, 0u,
-                                          32u, st));
+    SS_HIP(rocprim::radix_sort_pairs_desc(nullptr, bytes, vlen.p, vlen_sorted.p, iota.p, perm.p, (size_t)nv, 0u, 32u, st));
     DevBuf<unsigned char> tmp;
     SS_TRY(tmp.alloc(bytes));
-    SS_HIP(rocprim::radix_sort_pairs_desc(tmp.p, bytes, len.p, len_sorted.p, iota.p, out.perm.p, (size_t)in.rows, 0u,
-                                          32u, st));
-    hipLaunchKernelGGL(invert_perm_kernel, dim3(grid_for(in.rows, 256)), dim3(256), 0, st, out.perm.p, in.rows,
-                       out.inv.p);
+    SS_HIP(rocprim::radix_sort_pairs_desc(tmp.p, bytes, vlen.p, vlen_sorted.p, iota.p, perm.p, (size_t)nv, 0u, 32u, st));
+    hipLaunchKernelGGL(vrow_place_kernel, dim3(grid_for(nv, 256)), dim3(256), 0, st, perm.p, vstart.p, vlen.p,
+                       (int64_t)nv, out.vs.p, out.ve.p, out.inv.p);
     SS_LAUNCH_CHECK();
     out.sorted = true;
-    hipLaunchKernelGGL(sell_width_kernel, dim3((unsigned)ceil_div(nws * 64, 256)), dim3(256), 0, st, in.ptr.p,
-                       in.idx.p, in.rows, out.KC, out.nslices, out.nchunks, (const int*)out.perm.p, widthq.p);
+    out.nslices = (int)ceil_div((int64_t)nv, 64);
+    const int64_t nws2 = (int64_t)out.nslices * out.nchunks;
+    SS_TRY(out.off.alloc(nws2 + 1));
+    SS_TRY(widthq.alloc(nws2));
+    hipLaunchKernelGGL(sell_width_kernel, dim3((unsigned)ceil_div(nws2 * 64, 256)), dim3(256), 0, st, in.ptr.p,
+                       in.idx.p, (int64_t)nv, out.KC, out.nslices, out.nchunks, (const int*)out.vs.p,
+                       (const int*)out.ve.p, widthq.p);
     SS_LAUNCH_CHECK();
-    SS_TRY(exclusive_scan_int(widthq.p, out.off.p, nws));
-    SS_TRY(read_int(out.off.p + nws, &nq));
+    SS_TRY(exclusive_scan_int(widthq.p, out.off.p, nws2));
+    SS_TRY(read_int(out.off.p + nws2, &nq));
     SS_HIP(hipStreamSynchronize(st));
   }
+  const int64_t nws_f = (int64_t)out.nslices * out.nchunks;
   if (nq < 0 || (int64_t)nq * 256 >= (1LL << 40)) return fail(SS_EUNSUPPORTED, "SELL storage too large");
   out.nquads = nq;
   SS_TRY(out.idx.alloc((size_t)nq * 256));
   if (!out.binary) SS_TRY(out.val.alloc((size_t)nq * 256));
   else out.val.release();
   if (getenv("SS_SELL_PLAIN")) {
-    hipLaunchKernelGGL(sell_fill_kernel<T>, dim3((unsigned)ceil_div(nws * 64, 256)), dim3(256), 0, st, in.ptr.p,
-                       in.idx.p, in.val.p, in.rows, out.KC, out.nslices, out.nchunks, out.off.p,
-                       out.sorted ? (const int*)out.perm.p : (const int*)nullptr, out.idx.p,
+    hipLaunchKernelGGL(sell_fill_kernel<T>, dim3((unsigned)ceil_div(nws_f * 64, 256)), dim3(256), 0, st, in.ptr.p,
+                       in.idx.p, in.val.p, out.vrows, out.KC, out.nslices, out.nchunks, out.off.p,
+                       out.sorted ? (const int*)out.vs.p : (const int*)nullptr,
+                       out.sorted ? (const int*)out.ve.p : (const int*)nullptr, out.idx.p,
                        out.binary ? (T*)nullptr : out.val.p);
     SS_LAUNCH_CHECK();
   } else {
     DevBuf<int> perm;
     SS_TRY(perm.alloc(in.nnz));
-    hipLaunchKernelGGL(sell_fill_sched_kernel<T>, dim3((unsigned)nws), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p,
-                       in.rows, out.KC, out.nslices, out.nchunks, out.off.p,
-                       out.sorted ? (const int*)out.perm.p : (const int*)nullptr, perm.p, out.idx.p,
+    hipLaunchKernelGGL(sell_fill_sched_kernel<T>, dim3((unsigned)nws_f), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p,
+                       out.vrows, out.KC, out.nslices, out.nchunks, out.off.p,
+                       out.sorted ? (const int*)out.vs.p : (const int*)nullptr,
+                       out.sorted ? (const int*)out.ve.p : (const int*)nullptr, perm.p, out.idx.p,
                        out.binary ? (T*)nullptr : out.val.p);
     SS_LAUNCH_CHECK();
     SS_HIP(hipStreamSynchronize(st));

@@ -34,8 +34,13 @@ struct DevSell {
   // skewed row lengths (power-law graphs): rows are sorted by length before they are cut into slices so
   // that the 64 rows of a slice are equally long; results then come out in sorted order and are put back
   // by unpermute_kernel.  perm[sorted position] = row, inv[row] = sorted position.
+  // Rows longer than a wave's fair share are first split into "virtual rows" of bounded length (their
+  // partial scores are summed, in order, by the same epilogue), so a hot target cannot serialise a slice.
   bool sorted = false;
-  DevBuf<int> perm, inv;
+  int64_t vrows = 0;         // virtual rows (= slices * 64 rounded down); rows when not sorted
+  DevBuf<int> vs, ve;        // [vrows] CSR entry range of the virtual row at each sorted position
+  DevBuf<int> vfirst;        // [rows + 1] virtual ids of each real row
+  DevBuf<int> inv;           // [vrows] sorted position of each virtual id
 };
 
 // CSR cut into column chunks of SC columns, stored chunk-major with chunk-local 16-bit indices:
@@ -147,10 +152,11 @@ int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T
 
 template <class T>
 int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout);
-// out[r][t] = clean(in[r][inv[t]]): undo the row sort of a skew-sorted SELL operand (+ fused clean!)
+// out[r][t] = clean(sum_{v in vfirst[t]..vfirst[t+1]} in[r][inv[v]]): undo the row split + sort of a
+// skew-sorted SELL operand (+ fused clean!)
 template <class T>
-int launch_unpermute(const T* in, int64_t ldin, int64_t nrows, int64_t nt, const int* inv, const int* clean_deg,
-                     T* out, int64_t ldout);
+int launch_unpermute(const T* in, int64_t ldin, int64_t nrows, int64_t nt, const int* vfirst, const int* inv,
+                     const int* clean_deg, T* out, int64_t ldout);
 // clean! for leave-one-out rows: target t whose only edge belongs to query i
 template <class T>
 int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, int64_t nrows, T* out, int64_t ld);

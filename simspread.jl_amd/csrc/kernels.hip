@@ -509,7 +509,7 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
   a.nchunks = W.nchunks;
   a.KC = W.KC;
   a.K = W.cols;
-  a.M = W.rows;
+  a.M = W.sorted ? W.vrows : W.rows;
   a.B = B;
   a.R = R;
   a.ldr = ldr;
@@ -925,26 +925,27 @@ int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* o
 // ============================================================== unpermute (skew-sorted SELL results)
 template <class T>
 __global__ void unpermute_kernel(const T* __restrict__ in, int64_t ldin, int64_t nrows, int64_t nt,
-                                 const int* __restrict__ inv, const int* __restrict__ clean_deg, T* __restrict__ out,
-                                 int64_t ldout) {
+                                 const int* __restrict__ vfirst, const int* __restrict__ inv,
+                                 const int* __restrict__ clean_deg, T* __restrict__ out, int64_t ldout) {
   const int64_t r = blockIdx.y;
   const T* src = in + r * ldin;
   T* dst = out + r * ldout;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
-    const T v = src[inv[t]];  // the whole row of `in` sits in L2 while it is being gathered
+    T v = T(0);
+    for (int x = vfirst[t]; x < vfirst[t + 1]; ++x) v += src[inv[x]];  // the row of `in` sits in L2 meanwhile
     dst[t] = (clean_deg != nullptr && clean_deg[t] == 0) ? T(-99) : v;
   }
 }
 
 template <class T>
-int launch_unpermute(const T* in, int64_t ldin, int64_t nrows, int64_t nt, const int* inv, const int* clean_deg,
-                     T* out, int64_t ldout) {
+int launch_unpermute(const T* in, int64_t ldin, int64_t nrows, int64_t nt, const int* vfirst, const int* inv,
+                     const int* clean_deg, T* out, int64_t ldout) {
   if (nrows <= 0 || nt <= 0) return SS_OK;
   for (int64_t r0 = 0; r0 < nrows; r0 += 65535) {
     const int64_t nb = nrows - r0 < 65535 ? nrows - r0 : 65535;
     dim3 grid((unsigned)grid_1d(nt, 256, 64), (unsigned)nb);
-    hipLaunchKernelGGL(unpermute_kernel<T>, grid, dim3(256), 0, ctx().stream, in + r0 * ldin, ldin, nb, nt, inv,
-                       clean_deg, out + r0 * ldout, ldout);
+    hipLaunchKernelGGL(unpermute_kernel<T>, grid, dim3(256), 0, ctx().stream, in + r0 * ldin, ldin, nb, nt, vfirst,
+                       inv, clean_deg, out + r0 * ldout, ldout);
     SS_LAUNCH_CHECK();
   }
   return SS_OK;
@@ -990,7 +991,8 @@ int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, i
   template int launch_spmm_chunked_narrow<T>(const DevChunked<T>&, int, const T*, int64_t, int, T*, int64_t, \
                                              DevBuf<T>&);                                                   \
   template int launch_transpose<T>(const T*, int64_t, int64_t, int64_t, T*, int64_t);                       \
-  template int launch_unpermute<T>(const T*, int64_t, int64_t, int64_t, const int*, const int*, T*, int64_t); \
+  template int launch_unpermute<T>(const T*, int64_t, int64_t, int64_t, const int*, const int*, const int*, T*, \
+                                   int64_t);                                                                \
   template int launch_loo_clean_fix<T>(const DevCsr<T>&, const int*, int64_t, int64_t, T*, int64_t);
 SS_INSTANTIATE(float)
 SS_INSTANTIATE(double)

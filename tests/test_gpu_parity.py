@@ -358,6 +358,34 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
         assert_close(w32.spmm(R[:, :B].astype(np.float32)), W @ R[:, :B], np.float32)
     monkeypatch.setenv("SS_NARROW_CSR", "1")   # the L2-gather CSR kernel (what 16 < B <= 64 uses)
     assert_close(w.spmm(R[:, :5].copy()), W @ R[:, :5], np.float64)
+    # skewed rows: split the long rows into virtual rows, sort by length, put the scores back in order
+    monkeypatch.setenv("SS_SELL_SORT", "1")
+    monkeypatch.setenv("SS_SELL_LMAX", "256")
+    for dt in (np.float64, np.float32):
+        ws = ss.DeviceSpMat(W, dtype=dt)
+        assert_close(ws.spmm(R.astype(dt)), W @ R, dt)
+
+
+def test_power_law_graph_predict_with_sorted_split_operand(monkeypatch):
+    rng = np.random.default_rng(12)
+    ns, nt, nq = 600, 500, 77
+    deg = np.minimum((np.arange(1, ns + 1) ** -1.2) / np.mean(np.arange(1, ns + 1) ** -1.2) * 30, nt).astype(int) + 1
+    rng.shuffle(deg)
+    pt = np.arange(1, nt + 1) ** -1.2; pt /= pt.sum(); pt = pt[rng.permutation(nt)]
+    rows = np.repeat(np.arange(ns), deg)
+    cols = rng.choice(nt, size=rows.size, p=pt)
+    Y = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(ns, nt)); Y.data[:] = 1.0
+    Y[:, 3] = 0; Y.eliminate_zeros()   # one empty target for clean!
+    Xq, Xs, _ = O.synth_bipartite(nq, ns, ns, nt, 0.06, 0.01, seed=4, dtype=np.float64)
+    want = O.predict_factored(Xq, Xs, Y)
+    kt = np.asarray((Y != 0).sum(0)).ravel()
+    assert kt[3] == 0 and kt.max() > 300          # an empty target and a hot one
+    want[:, kt == 0] = -99.0
+    for force in ("1", "0"):
+        monkeypatch.setenv("SS_SELL_SORT", force)
+        monkeypatch.setenv("SS_SELL_LMAX", "256")
+        g = ss.DeviceGraph.from_sparse(Xq, Xs, Y, dtype=np.float64)
+        assert_close(g.predict("query", clean=True), want, np.float64)
 
 
 # ----------------------------------------------------------------------------- BASELINE config 2 at full size
