@@ -121,6 +121,16 @@ int ss_graph_create_dense_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt,
                               const double* Sq, int64_t ldq, const double* Ss, int64_t lds,
                               const double* Y, int64_t ldy, int apply_cutoff, double alpha,
                               int weighted, int mem, ss_graph** out);
+/* Dense-similarity regime (thresholded similarity too full for CSR, e.g. 90 % of 50k x 50k): the raw
+ * similarities stay dense on the device and featurize's cutoff (src/core.jl:106-112) is applied inside
+ * the stage-1 product, which runs as an fp32-input MFMA GEMM; the labels Y stay sparse (CSR, ns x nt).
+ * Sq (nq x ns) and Ss (ns x ns) are column-major raw similarities whose columns are the features named
+ * after the sources; nq may be 0.  Serves ss_predict_f32(SS_ROWS_QUERY) and ss_predict_loo_f32.
+ * fp32 only (the exact-fp32 matrix instruction); there is no _f64 form. */
+int ss_graph_create_similarity_f32(int64_t nq, int64_t ns, int64_t nt,
+                                   const float* Sq, int64_t ldq, const float* Ss, int64_t lds,
+                                   const int64_t* y_ptr, const int32_t* y_idx, const float* y_val,
+                                   int index_base, float alpha, int weighted, int mem, ss_graph** out);
 /* General form for caller-built adjacency matrices: predict accepts ANY named A, B
  * (src/core.jl:402-425; the reference's own test passes hand-written 9 x 9 matrices,
  * test/runtests.jl:120-158).  With n nodes, the caller passes

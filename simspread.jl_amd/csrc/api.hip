@@ -3,6 +3,7 @@
 // checks, staging of caller buffers, the stage-1 / stage-2 launch sequence, event timing.
 #include <cstdlib>
 #include <new>
+#include <type_traits>
 
 #include "graph.hpp"
 
@@ -257,6 +258,44 @@ static int graph_create_general_impl(int64_t n, int64_t nr, int64_t nc, const in
   return SS_OK;
 }
 
+// dense-similarity graph (fp32): raw similarities resident, labels sparse
+static int graph_create_similarity_impl(int64_t nq, int64_t ns, int64_t nt, const float* Sq, int64_t ldq,
+                                        const float* Ss, int64_t lds, const int64_t* y_ptr, const int32_t* y_idx,
+                                        const float* y_val, int index_base, float alpha, int weighted, int mem,
+                                        ss_graph** out) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (!out) return fail(SS_EINVAL, "out handle pointer is NULL");
+  *out = nullptr;
+  if (nq < 0 || ns < 0 || nt < 0) return fail(SS_EINVAL, "negative node count");
+  if ((nq > 0 && (!Sq || ldq < nq)) || (ns > 0 && (!Ss || lds < ns)))
+    return fail(SS_EINVAL, "similarity block: NULL pointer or ld < rows");
+  GraphBox<float>* box = new (std::nothrow) GraphBox<float>();
+  if (!box) return fail(SS_ENOMEM, "host allocation failed");
+  box->dtype = 4;
+  Graph<float>& g = box->g;
+  g.nq = nq; g.ns = ns; g.nf = ns; g.nt = nt;
+  DenseSim<float>& d = g.dense;
+  d.on = true; d.nq = nq; d.ns = ns; d.nf = ns; d.alpha = alpha; d.weighted = weighted != 0;
+  hipStream_t st = ctx().stream;
+  auto stage = [&](const float* src, int64_t rows, int64_t ld, DevBuf<float>& dst) -> int {
+    SS_TRY(dst.alloc((size_t)rows * (size_t)ns));
+    if (rows == 0 || ns == 0) return SS_OK;
+    SS_HIP(hipMemcpy2DAsync(dst.p, rows * sizeof(float), src, ld * sizeof(float), rows * sizeof(float), ns,
+                            mem == SS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    return SS_OK;
+  };
+  int rc = stage(Sq, nq, ldq, d.Sq);
+  if (rc == SS_OK) rc = stage(Ss, ns, lds, d.Ss);
+  if (rc == SS_OK) rc = csr_from_user<float>(ns, nt, y_ptr, y_idx, y_val, index_base, mem, g.Ys);
+  if (rc == SS_OK) rc = csr_transpose(g.Ys, g.YsT);
+  if (rc == SS_OK) rc = graph_finalize_general_targets(g);
+  if (rc == SS_OK) rc = dense_degrees(g);
+  if (rc != SS_OK) { delete box; return rc; }
+  *out = reinterpret_cast<ss_graph*>(box);
+  return SS_OK;
+}
+
 // stage-2 operand of a graph: W = Ys' cut for the tile width of this precision
 template <class T>
 static int graph_sell(Graph<T>& g) {
@@ -319,7 +358,7 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
   const int64_t nrows = row_end - row_begin;
   const int64_t nj = g.ns;
   SS_TRY(graph_sell(g));
-  SS_TRY(graph_chunked(g, kind == SS_ROWS_SOURCE));
+  if (!g.dense.on) SS_TRY(graph_chunked(g, kind == SS_ROWS_SOURCE));
   const int64_t rb = transfer_batch_rows(nrows, nj, sizeof(T));
   // the transfer block lives in the handle so that repeated predictions do not re-allocate
   const size_t need = (size_t)rb * (size_t)(nj > 0 ? nj : 1);
@@ -329,7 +368,15 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
     const int64_t nb = (nrows - r0 < rb) ? (nrows - r0) : rb;
     {
       StageTimer t1(ST_TRANSFER);
-      if (kind == 2) {
+      if (g.dense.on) {
+        if constexpr (std::is_same<T, float>::value) {
+          const bool loo = (kind == 2);
+          SS_TRY(launch_transfer_dense(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
+                                       row_begin + r0, nb, Tbuf.p, nj));
+        } else {
+          return fail(SS_EUNSUPPORTED, "the dense-similarity path is fp32 only");
+        }
+      } else if (kind == 2) {
         SS_TRY(launch_transfer_loo<T>(g.Xs, g.XsTc, g.kf.p, g.ks.p, row_begin + r0, nb, Tbuf.p, nj));
       } else if (kind == SS_ROWS_QUERY) {
         const DevCsr<T>* L[2] = {&g.Xq, nullptr};
@@ -383,8 +430,10 @@ static int predict_impl(ss_graph* h, int kind, int64_t row_begin, int64_t row_en
   const int64_t limit = (kind == SS_ROWS_QUERY) ? g.nq : g.ns;
   if (g.general && kind != SS_ROWS_QUERY)
     return fail(SS_EINVAL, "a general graph serves SS_ROWS_QUERY only");
+  if (g.dense.on && kind == SS_ROWS_SOURCE)
+    return fail(SS_EUNSUPPORTED, "source rows are not served by the dense-similarity path yet");
   if (kind == 2) {
-    if (g.nq != 0 || g.ns != g.nf)
+    if ((!g.dense.on && g.nq != 0) || g.ns != g.nf)
       return fail(SS_EINVAL, "leave-one-out needs a graph with nq == 0 and ns == nf (feature j named after source j)");
   } else if (kind != SS_ROWS_QUERY && kind != SS_ROWS_SOURCE) {
     return fail(SS_EINVAL, "rows_kind must be SS_ROWS_QUERY or SS_ROWS_SOURCE");
@@ -750,6 +799,13 @@ int ss_graph_create_general_f64(int64_t n, int64_t nr, int64_t nc, const int64_t
                                 int mem, ss_graph** out) {
   return graph_create_general_impl<double>(n, nr, nc, l_ptr, l_idx, l_val, b_ptr, b_idx, b_val, w_ptr, w_idx, w_val,
                                            index_base, mem, out);
+}
+
+int ss_graph_create_similarity_f32(int64_t nq, int64_t ns, int64_t nt, const float* Sq, int64_t ldq, const float* Ss,
+                                   int64_t lds, const int64_t* y_ptr, const int32_t* y_idx, const float* y_val,
+                                   int index_base, float alpha, int weighted, int mem, ss_graph** out) {
+  return graph_create_similarity_impl(nq, ns, nt, Sq, ldq, Ss, lds, y_ptr, y_idx, y_val, index_base, alpha, weighted,
+                                      mem, out);
 }
 
 int ss_graph_destroy(ss_graph* h) {

@@ -864,6 +864,19 @@ int graph_finalize_general(Graph<T>& g) {
   return SS_OK;
 }
 
+int graph_finalize_general_targets(Graph<float>& g) {
+  hipStream_t st = ctx().stream;
+  SS_TRY(g.kt.alloc(g.nt));
+  SS_TRY(g.inv_kt.alloc(g.nt));
+  if (g.nt > 0) {
+    hipLaunchKernelGGL(degree_kernel<float>, dim3(grid_for(g.nt, 256)), dim3(256), 0, st, g.YsT.ptr.p,
+                       (const int*)nullptr, g.nt, g.kt.p, g.inv_kt.p);
+    SS_LAUNCH_CHECK();
+  }
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
 #define SS_INSTANTIATE(T)                                                                                      \
   template int csr_from_user<T>(int64_t, int64_t, const int64_t*, const int32_t*, const T*, int, int, DevCsr<T>&); \
   template int csr_from_dense<T>(const T*, int64_t, int64_t, int64_t, bool, T, bool, int, DevCsr<T>&);         \

@@ -59,10 +59,23 @@ struct DevChunked {
   DevBuf<T> val;               // [stored + 64]
 };
 
+// Dense-similarity regime: the raw similarities stay dense on the device (column-major), the cutoff is
+// applied inside the stage-1 GEMM (dense.hip).
+template <class T>
+struct DenseSim {
+  bool on = false;
+  int64_t nq = 0, ns = 0, nf = 0;
+  T alpha = T(0);
+  bool weighted = true;
+  DevBuf<T> Sq, Ss;       // nq x nf and ns x nf, column-major, ld = rows
+  DevBuf<T> inv_kf_m1;    // 1/(kf-1): leave-one-out coefficient
+};
+
 template <class T>
 struct Graph {
   int64_t nq = 0, ns = 0, nf = 0, nt = 0;
-  bool general = false;  // built by ss_graph_create_general: only Xq, XsT, YsT and kf == ks are set
+  bool general = false;
+  DenseSim<T> dense;  // built by ss_graph_create_general: only Xq, XsT, YsT and kf == ks are set
   DevCsr<T> Xq;    // nq x nf
   DevCsr<T> Xs;    // ns x nf
   DevCsr<T> XsT;   // nf x ns
@@ -104,6 +117,7 @@ template <class T>
 int graph_finalize(Graph<T>& g);  // transposes + degrees
 template <class T>
 int graph_finalize_general(Graph<T>& g);  // degrees = row counts of B (held in XsT)
+int graph_finalize_general_targets(Graph<float>& g);  // kt / inv_kt from YsT only
 
 // ---- kernels.hip (launch wrappers; everything is enqueued on ctx().stream)
 template <class T>
@@ -149,6 +163,11 @@ int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64
 // stage 2, narrow (B <= 64): F[m][b] = sum_k W[m][k] * R[k][b]   (row-major operands, CSR streamed once)
 template <class T>
 int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
+
+// ---- dense.hip (fp32 only: fp32-input MFMA)
+int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
+                          int64_t row_begin, int64_t nrows, float* out, int64_t ldo);
+int dense_degrees(Graph<float>& g);
 
 template <class T>
 int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout);

@@ -160,6 +160,53 @@ class DeviceGraph:
         return cls(h, dtype)
 
     @classmethod
+    def from_similarity(cls, Sq, Ss, Y, alpha: float, weighted: bool = True):
+        """Dense-similarity regime (fp32): raw similarities Sq (nq x ns, may be None) and Ss (ns x ns) stay dense
+        on the device, the cutoff is applied inside the MFMA stage-1 product; Y (ns x nt) is sparse.  Inputs:
+        numpy arrays / scipy matrix on the host, or torch CUDA tensors for Sq, Ss with Y = (ptr, idx, val) device
+        CSR.  Serves predict("query") and predict_loo()."""
+        import scipy.sparse as sp
+        lib = L.lib()
+        dev = _is_torch(Ss)
+        keep = []
+
+        def dense_cm(a):
+            if a is None:
+                return None, 1, 0
+            if dev:
+                import torch
+                t = a.to(torch.float32).t().contiguous()   # row-major transpose == column-major original
+                keep.append(t)
+                return t.data_ptr(), a.shape[0], a.shape[0]
+            arr = np.asfortranarray(np.asarray(a, dtype=np.float32))
+            keep.append(arr)
+            return arr.ctypes.data, max(arr.shape[0], 1), arr.shape[0]
+
+        pq, ldq, nq = dense_cm(Sq)
+        ps, lds, ns = dense_cm(Ss)
+        if dev:
+            yp, yi, yv = Y[0], Y[1], Y[2]
+            nt = int(Y[3])
+            yptr, yidx, yval = yp.data_ptr(), yi.data_ptr(), (None if yv is None else yv.data_ptr())
+            mem = L.SS_MEM_DEVICE
+        else:
+            Y = sp.csr_matrix(Y)
+            if Y.shape[0] != ns:
+                raise AssertionError("Labels and features have different number of source nodes")
+            nt = Y.shape[1]
+            parts = _csr_parts(Y, np.float32)
+            keep.append(parts)
+            yptr, yidx, yval = _ptr(parts[0]), _ptr(parts[1]), _ptr(parts[2])
+            mem = L.SS_MEM_HOST
+        h = C.c_void_p()
+        L.check(lib.ss_graph_create_similarity_f32(nq, ns, nt, pq, ldq, ps, lds, yptr, yidx, yval, 0,
+                                                   C.c_float(alpha), 1 if weighted else 0, mem, C.byref(h)))
+        if dev:
+            L.check(lib.ss_synchronize())
+        del keep
+        return cls(h, np.float32)
+
+    @classmethod
     def general(cls, A_rows, B, B_cols_T, dtype=np.float64):
         """predict for caller-built A, B (src/core.jl:402-425): A_rows = A[rows, :], B, B_cols_T = B[:, cols]'."""
         import scipy.sparse as sp

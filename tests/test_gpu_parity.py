@@ -407,3 +407,40 @@ def test_config2_full_size_sampled_rows_and_linearity():
     # ... and resource is conserved: every query's scores sum to sum_s T[q,s] * (#targets of s)
     T = O.transfer_factored(f64[0][:64], f64[1], f64[2])
     np.testing.assert_allclose(got[:64].astype(np.float64).sum(1), T @ np.asarray((f64[2] != 0).sum(1)).ravel(), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- dense-similarity regime (MFMA stage 1)
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("shape", [(70, 333, 41), (1, 64, 5), (130, 129, 300)])
+def test_dense_similarity_path_query_and_loo(shape, weighted):
+    nq, ns, nt = shape
+    rng = np.random.default_rng(ns)
+    Ss = rng.random((ns, ns)).astype(np.float32); Ss = ((Ss + Ss.T) / 2).astype(np.float32); np.fill_diagonal(Ss, 1.0)
+    Sq = rng.random((nq, ns)).astype(np.float32)
+    Y = sp.random(ns, nt, density=0.08, format="csr", random_state=rng, dtype=np.float32); Y.data[:] = 1.0
+    alpha = np.float32(0.35)   # ~65 % fill: far denser than the CSR path is meant for
+    Ss[3, 7] = Ss[7, 3] = alpha  # exactly alpha: kept
+    g = ss.DeviceGraph.from_similarity(Sq, Ss, Y, alpha=float(alpha), weighted=weighted)
+    Xq = O.cutoff(Sq.astype(np.float64), float(alpha), weighted)
+    Xs = O.cutoff(Ss.astype(np.float64), float(alpha), weighted)
+    Y64 = Y.astype(np.float64)
+    kf, ks, kt = g.degrees()
+    okf, oks, okt = O.degrees(Xs, Y64)
+    np.testing.assert_array_equal(kf, okf); np.testing.assert_array_equal(ks, oks); np.testing.assert_array_equal(kt, okt)
+    assert_close(g.predict("query"), O.predict_factored(Xq, Xs, Y64), np.float32)
+    want = O.predict_loo_factored(Xs, Y64, clean_flag=True)
+    assert_close(g.predict_loo(clean=True), want, np.float32)
+    lo, hi = ns // 3, ns - 1
+    assert_close(g.predict_loo(lo, hi, clean=True, layout="col"), want[lo:hi], np.float32)
+    with pytest.raises(ss.SimSpreadError):
+        g.predict("source")
+
+
+def test_dense_similarity_equals_sparse_path_on_the_same_input():
+    rng = np.random.default_rng(77)
+    ns, nq, nt = 500, 100, 64
+    Ss = rng.random((ns, ns)).astype(np.float32); Sq = rng.random((nq, ns)).astype(np.float32)
+    Y = (rng.random((ns, nt)) < 0.05).astype(np.float32)
+    a = ss.DeviceGraph.from_similarity(Sq, Ss, sp.csr_matrix(Y), alpha=0.8, weighted=True).predict("query")
+    b = ss.DeviceGraph.from_dense(Sq, Ss, Y, alpha=np.float32(0.8), weighted=True, dtype=np.float32).predict("query")
+    np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-9)
