@@ -162,6 +162,8 @@ struct SubRows {
   T cf[U];
   unsigned short j[U];
   T v[U];
+  unsigned short j2[U];  // entries 64..127 of the sub-row, fetched only when it is that long (wave-uniform)
+  T v2[U];
 };
 
 template <class T, int U>
@@ -178,6 +180,13 @@ __device__ __forceinline__ void subrows_load(SubRows<T, U>& s, int first, int b_
     const T* pv = mval + s.b[u];
     s.j[u] = pi[lane];
     s.v[u] = pv[lane];
+    // With the chunk sized for a mean sub-row of ~60 entries, ~40 % of the sub-rows are longer than one
+    // wave: their second half must be prefetched like the first (a dependent load inside the fold
+    // stalls the whole batch), so it is issued here under a wave-uniform branch.
+    if (s.n[u] > 64) {
+      s.j2[u] = pi[64 + lane];
+      s.v2[u] = pv[64 + lane];
+    }
   }
 }
 
@@ -191,15 +200,19 @@ __device__ __forceinline__ void subrows_fold(const SubRows<T, U>& s, int first, 
   for (int u = 0; u < U; ++u) {
     const int j = lane < s.n[u] ? (int)s.j[u] : dummy;
     acc[j] = fma(s.cf[u], s.v[u], acc[j]);
+    if (s.n[u] > 64) {
+      const int k = 64 + lane < s.n[u] ? (int)s.j2[u] : dummy;
+      acc[k] = fma(s.cf[u], s.v2[u], acc[k]);
+    }
     nmax = s.n[u] > nmax ? s.n[u] : nmax;
   }
-  if (nmax > 64) {  // rare: a sub-row longer than one wave (bounds re-read by lane index, no register arrays)
+  if (nmax > 128) {  // rare: a sub-row longer than two waves (bounds re-read by lane index, no register arrays)
 #pragma unroll 1
     for (int u = 0; u < U; ++u) {
       const int n = __builtin_amdgcn_readlane(n_l, first + u);
       const unsigned b = (unsigned)__builtin_amdgcn_readlane(b_l, first + u);
       const T cf = BitsOf<T>::bcast(cf_l, first + u);
-      for (int x = 64 + lane; x < n; x += 64) {
+      for (int x = 128 + lane; x < n; x += 64) {
         const int j = midx[b + x];
         acc[j] = fma(cf, mval[b + x], acc[j]);
       }
