@@ -1,0 +1,96 @@
+"""BASELINE.json configs 3-5 at (or near) their full sizes, through the same C ABI: a block of folds is scored
+on the GPU and sampled folds are checked against the CPU oracle; size-independent properties cover the rest."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import simspread_jl_amd as ss
+from oracle import simspread_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    ss.init(0)
+    ss.use_torch_stream()
+
+
+def _host_csr(ptr, idx, val, shape):
+    v = np.ones(idx.numel()) if val is None else val.cpu().numpy().astype(np.float64)
+    return sp.csr_matrix((v, idx.cpu().numpy(), ptr.cpu().numpy()), shape=shape)
+
+
+def test_config3_100k_loo_block_vs_oracle():
+    """C3: 100k x 100k, 1 % (nnz 1e8 each), leave-one-out; one 512-fold block of the 100k folds."""
+    import torch
+    from tools.c3_loo import rand_csr, rand_sym_csr
+    n, folds = 100_000, 512
+    gen = torch.Generator(device="cuda"); gen.manual_seed(20250222 + 3)
+    xp, xi = rand_sym_csr(n, 0.01, gen)
+    yp, yi = rand_csr(n, n, 0.01, gen)
+    xv = (0.5 + 0.5 * torch.rand(xi.numel(), device="cuda", generator=gen)).float()
+    g = ss.DeviceGraph.from_device_csr(0, n, n, n, None, (xp, xi, xv), (yp, yi, None), dtype=np.float32)
+    assert g.nnz_xs > 9.9e7 and g.nnz_ys > 9.9e7
+    lo = 50_000                                     # a block in the middle: what rank 4 of 8 would start with
+    out = torch.empty((folds, n), dtype=torch.float32, device="cuda")
+    g.predict_loo(lo, lo + folds, clean=True, out=out)
+    X, Y = _host_csr(xp, xi, xv, (n, n)), _host_csr(yp, yi, None, (n, n))
+    qs = [lo, lo + 255, lo + folds - 1]
+    want = O.predict_loo_factored(X, Y, clean_flag=True, queries=qs)
+    got = out[[q - lo for q in qs]].cpu().numpy().astype(np.float64)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-5
+    assert ((want == 0) <= (got == 0)).all()
+    # the same folds scored as part of a different block must give bit-identical rows (fold independence,
+    # the property the 8-GPU sharding relies on)
+    out2 = torch.empty((256, n), dtype=torch.float32, device="cuda")
+    g.predict_loo(lo + 128, lo + 384, clean=True, out=out2)
+    assert torch.equal(out2, out[128:384])
+
+
+def test_config5_power_law_block_vs_oracle():
+    """C5: Zipf(1.2) source degrees and target popularity, 200k nodes, hot rows/columns at random positions."""
+    import torch
+    from tools.c3_loo import rand_sym_csr
+    from tools.c5_powerlaw import zipf_bipartite
+    n, folds = 100_000, 256
+    gen = torch.Generator(device="cuda"); gen.manual_seed(20250222 + 5)
+    xp, xi = rand_sym_csr(n, 0.01, gen)
+    yp, yi = zipf_bipartite(n, n, 1000, 1.2, gen)
+    xv = (0.5 + 0.5 * torch.rand(xi.numel(), device="cuda", generator=gen)).float()
+    g = ss.DeviceGraph.from_device_csr(0, n, n, n, None, (xp, xi, xv), (yp, yi, None), dtype=np.float32)
+    kf, ks, kt = g.degrees()
+    assert kt.max() > 50_000 and np.median(kt) < 100      # a handful of hot targets, a long cold tail
+    out = torch.empty((folds, n), dtype=torch.float32, device="cuda")
+    g.predict_loo(0, folds, clean=True, out=out)
+    X, Y = _host_csr(xp, xi, xv, (n, n)), _host_csr(yp, yi, None, (n, n))
+    qs = [0, 100, folds - 1]
+    want = O.predict_loo_factored(X, Y, clean_flag=True, queries=qs)
+    got = out[qs].cpu().numpy().astype(np.float64)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-5
+    assert ((want == -99) == (got == -99)).all()
+
+
+def test_config4_dense_similarity_cutoff_sweep():
+    """C4 (reduced to 12k sources so the fp64 check stays in seconds; tools/c4_dense.py runs the 50k size):
+    raw similarity dense, cutoff sweep, MFMA stage 1, both weightings."""
+    import torch
+    from tools.c3_loo import rand_csr
+    n, nt, folds = 12_000, 3_000, 512
+    gen = torch.Generator(device="cuda"); gen.manual_seed(20250222 + 4)
+    S = torch.rand((n, n), device="cuda", generator=gen)
+    S = (S + S.t()) * 0.5
+    S.fill_diagonal_(1.0)
+    yp, yi = rand_csr(n, nt, 0.01, gen)
+    Sh = S.cpu().numpy().astype(np.float64)
+    Y = _host_csr(yp, yi, None, (n, nt))
+    out = torch.empty((folds, nt), dtype=torch.float32, device="cuda")
+    for alpha, weighted in ((0.1, True), (0.5, False), (0.9, True)):
+        g = ss.DeviceGraph.from_similarity(None, S, (yp, yi, None, nt), alpha=alpha, weighted=weighted)
+        g.predict_loo(1000, 1000 + folds, clean=True, out=out)
+        X = sp.csr_matrix(O.cutoff(Sh, float(np.float32(alpha)), weighted))
+        qs = [1000, 1255, 1000 + folds - 1]
+        want = O.predict_loo_factored(X, Y, clean_flag=True, queries=qs)
+        got = out[[q - 1000 for q in qs]].cpu().numpy().astype(np.float64)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (alpha, weighted)
+        g.close()
