@@ -28,6 +28,8 @@ class NamedMatrix:
     """Matrix + row/column names (stand-in for NamedArrays.NamedMatrix used throughout the reference)."""
 
     def __init__(self, array, rows: Optional[Sequence] = None, cols: Optional[Sequence] = None):
+        # NamedArray([1 0; 0 1]) keeps Int elements in Julia (they print bare in save); remember that
+        self.integer = np.issubdtype(np.asarray(array).dtype, np.integer)
         self.array = np.array(array, dtype=np.float64, ndmin=2)
         r, c = self.array.shape
         # NamedArrays' default names are "1".."n"
@@ -338,3 +340,57 @@ def _rows_of(A, rownames):
 
 
 clean_ = clean  # Julia's `clean!`
+
+
+# --------------------------------------------------------------------------- split / save ("next" rows of SURVEY 8f)
+def split(y: NamedMatrix, k: int, seed: int = 1) -> List[List[str]]:
+    """k-fold grouping of the source names: shuffle, then source i (1-based) goes to fold mod(i, k) + 1
+    (src/core.jl:11-25).  The shuffle of the reference is Julia's MersenneTwister(seed) + shuffle!, which is
+    not reproduced bit for bit (its only test is skipped, test/runtests.jl:34: parity unpinned); numpy's
+    PCG64 is used instead, so the groups differ from Julia's for the same seed but have the same sizes."""
+    sources = list(y.names(1))
+    rng = np.random.default_rng(seed)
+    rng.shuffle(sources)
+    groups: List[List[str]] = [[] for _ in range(k)]
+    for i, s in enumerate(sources, start=1):
+        groups[i % k].append(s)
+    return groups
+
+
+def _julia_number(x) -> str:
+    """How Julia's join/print shows a matrix element: Ints bare, floats shortest round-trip with a trailing .0"""
+    if isinstance(x, (int, np.integer)):
+        return str(int(x))
+    f = float(x)
+    if f == int(f) and abs(f) < 1e16:
+        return f"{int(f)}.0" if not np.isnan(f) else "NaN"
+    return repr(f)
+
+
+def save(filepath: str, *args, delimiter: str = "\t") -> None:
+    """save(filepath, yhat, y; delimiter) | save(filepath, fidx, yhat, y; delimiter)   (src/core.jl:503-522,542-561).
+
+    Appends one line per (query, target): fold, "query", "target", score, label.  Without a fold index the
+    first column is the 1-based position of the query.  Integer-valued NamedMatrix payloads built from integer
+    input print bare (test/data/save1-4); this mirror keeps that by remembering the input dtype."""
+    if len(args) == 2:
+        fidx, (yhat, y) = None, args
+    elif len(args) == 3:
+        fidx, yhat, y = args
+    else:
+        raise TypeError("save: no method matching these arguments")
+    queries, targets = y.names(1), y.names(2)
+    qi = {n: i for i, n in enumerate(yhat.rows)}
+    ti = {n: i for i, n in enumerate(yhat.cols)}
+    yq = {n: i for i, n in enumerate(y.rows)}
+    yt = {n: i for i, n in enumerate(y.cols)}
+
+    def show(M, v):
+        return _julia_number(int(v)) if getattr(M, "integer", False) else _julia_number(v)
+
+    with open(filepath, "a+") as f:
+        for pos, q in enumerate(queries, start=1):
+            for t in targets:
+                row = [str(pos if fidx is None else fidx), f'"{q}"', f'"{t}"',
+                       show(yhat, yhat.array[qi[q], ti[t]]), show(y, y.array[yq[q], yt[t]])]
+                f.write(delimiter.join(row) + "\n")
