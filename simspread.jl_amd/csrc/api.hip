@@ -578,6 +578,21 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
     StageTimer t2(ST_SPMM);
     SS_TRY(launch_spmm_chunked_narrow<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
     timing_count(ST_NSPMM, 1);
+  } else if (narrow && std::is_same<T, float>::value && !use_csr_gather) {
+    // 16 < B <= 64: accumulators in registers, R chunks in LDS, W read once
+    if constexpr (std::is_same<T, float>::value) {
+      if (m.pairs.KC == 0) {
+        int kc = 640;  // 640 rows x 64 floats = 160 KB
+        if (const char* e = getenv("SS_NARROW_CHUNK")) {
+          const int v = atoi(e);
+          if (v >= 16 && v < kc) kc = v;
+        }
+        SS_TRY(pairs_build(m.csr, kc, 256, m.pairs));
+      }
+      StageTimer t2(ST_SPMM);
+      SS_TRY(launch_spmm_regacc(m.pairs, Rd, ldr_d, (int)B, Fd, ldf_d));
+      timing_count(ST_NSPMM, 1);
+    }
   } else if (narrow) {
     StageTimer t2(ST_SPMM);
     SS_TRY(launch_spmm_csr_narrow<T>(m.csr, Rd, ldr_d, (int)B, Fd, ldf_d));

@@ -91,12 +91,23 @@ struct Graph {
   DevBuf<T> Sws;  // workspace: sorted-order scores of a skew-sorted stage-2 operand
 };
 
+// Chunk-major (row offset, value) pairs for the register-accumulator SpMM (16 < B <= 64, fp32): the
+// 32-bit first word is the byte offset of the row of R inside the LDS tile, so an entry is consumed as a
+// scalar pair (s_load) and one ds_read.
+struct DevPairs {
+  int64_t rows = 0, cols = 0, nnz = 0;
+  int KC = 0, nchunks = 0, row_bytes = 0;
+  DevBuf<int> off;        // [nchunks*rows + 1]
+  DevBuf<uint2> ent;      // [nnz + 8]
+};
+
 template <class T>
 struct SpMat {
   DevCsr<T> csr;
   DevSell<T> sell;
   int sell_qt = 0;
   DevChunked<T> narrow[5];  // quad-aligned chunked operands for B <= 1, 2, 4, 8, 16 (built lazily)
+  DevPairs pairs;           // operand of the register-accumulator kernel (16 < B <= 64, fp32)
   DevBuf<T> partial;        // [nchunks][rows][BV] partial sums of the narrow kernel
 };
 
@@ -160,6 +171,9 @@ int narrow_chunk_cols(int bv);  // KC for a padded width bv
 template <class T>
 int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
                                DevBuf<T>& partial);
+// stage 2, 16 < B <= 64 (fp32): accumulators in registers (lane = column), R chunk in LDS, entries by s_load
+int pairs_build(const DevCsr<float>& in, int KC, int row_bytes, DevPairs& out);
+int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf);
 // stage 2, narrow (B <= 64): F[m][b] = sum_k W[m][k] * R[k][b]   (row-major operands, CSR streamed once)
 template <class T>
 int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);

@@ -907,6 +907,105 @@ int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64
   return SS_OK;
 }
 
+// ============================================================== stage 2, 16 < B <= 64: accumulators in registers
+// F = W*R with lane = column of R/F.  A wave owns up to RA_NV consecutive rows of W, one accumulator
+// register per row; the workgroup walks the column chunks of W, keeps the chunk's rows of R in LDS
+// ([KC][64] floats, all 160 KB) and every entry (tile row offset, value) is a scalar pair (s_load)
+// followed by one conflict-free ds_read_b32 and one FMA across the 64 columns.  No partial sums ever
+// leave the registers; W is read once (chunk-major), R once per workgroup.
+struct RegAccArgs {
+  const int* off;
+  const uint2* ent;
+  int64_t M, K;
+  int KC, nchunks, B;
+  int rpw;  // rows per wave (<= RA_NV)
+  const float* R;
+  int64_t ldr;
+  float* F;
+  int64_t ldf;
+};
+constexpr int RA_NV = 32;
+constexpr int RA_THREADS = 1024;
+
+__global__ void __launch_bounds__(RA_THREADS) spmm_regacc_kernel(RegAccArgs a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);  // [KC][64]
+  const char* tb = reinterpret_cast<const char*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int64_t r0 = ((int64_t)blockIdx.x * nwaves + wave) * a.rpw;
+  int nr = 0;
+  if (r0 < a.M) nr = (int)((a.M - r0 < a.rpw) ? (a.M - r0) : a.rpw);
+  nr = __builtin_amdgcn_readfirstlane(nr);
+  float acc[RA_NV];
+#pragma unroll
+  for (int j = 0; j < RA_NV; ++j) acc[j] = 0.0f;
+  const uint2* __restrict__ ent = a.ent;
+  const int lane4 = lane * 4;
+
+  for (int c = 0; c < a.nchunks; ++c) {
+    const int64_t k0 = (int64_t)c * a.KC;
+    const int kn = (int)((a.K - k0 < a.KC) ? (a.K - k0) : a.KC);
+    if (c) __syncthreads();
+    for (int e = tid; e < a.KC * 64; e += blockDim.x) {
+      const int k = e >> 6, b = e & 63;
+      tile[e] = (k < kn && b < a.B) ? a.R[(k0 + k) * a.ldr + b] : 0.0f;
+    }
+    __syncthreads();
+    int offv = 0;
+    if (lane <= nr && nr > 0) offv = a.off[(int64_t)c * a.M + r0 + lane];
+#pragma unroll
+    for (int j = 0; j < RA_NV; ++j) {
+      if (j < nr) {
+        const int b = __builtin_amdgcn_readlane(offv, j);
+        const int e = __builtin_amdgcn_readlane(offv, j + 1);
+        for (int x = b; x < e; x += 4) {
+          const uint2 q0 = ent[x], q1 = ent[x + 1], q2 = ent[x + 2], q3 = ent[x + 3];  // 8 entries of slack at the end
+          const float w0 = __uint_as_float(q0.y);
+          const float w1 = x + 1 < e ? __uint_as_float(q1.y) : 0.0f;
+          const float w2 = x + 2 < e ? __uint_as_float(q2.y) : 0.0f;
+          const float w3 = x + 3 < e ? __uint_as_float(q3.y) : 0.0f;
+          // offsets of entries past the row end belong to the next row of the same chunk (or the zero slack):
+          // always inside the tile
+          const float t0 = *reinterpret_cast<const float*>(tb + q0.x + lane4);
+          const float t1 = *reinterpret_cast<const float*>(tb + q1.x + lane4);
+          const float t2 = *reinterpret_cast<const float*>(tb + q2.x + lane4);
+          const float t3 = *reinterpret_cast<const float*>(tb + q3.x + lane4);
+          acc[j] = fmaf(w0, t0, acc[j]);
+          acc[j] = fmaf(w1, t1, acc[j]);
+          acc[j] = fmaf(w2, t2, acc[j]);
+          acc[j] = fmaf(w3, t3, acc[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RA_NV; ++j)
+    if (j < nr && lane < a.B) a.F[(r0 + j) * a.ldf + lane] = acc[j];
+}
+
+int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf) {
+  if (W.rows <= 0 || B <= 0) return SS_OK;
+  if (B > 64 || W.row_bytes != 256) return fail(SS_EINVAL, "register-accumulator SpMM serves B <= 64");
+  RegAccArgs a{};
+  a.off = W.off.p; a.ent = W.ent.p; a.M = W.rows; a.K = W.cols; a.KC = W.KC; a.nchunks = W.nchunks; a.B = B;
+  a.R = R; a.ldr = ldr; a.F = F; a.ldf = ldf;
+  const int nw = RA_THREADS / 64;
+  int64_t rpw = ceil_div(ceil_div(W.rows, ctx().num_cu), nw);
+  if (rpw > RA_NV) rpw = RA_NV;
+  if (rpw < 1) rpw = 1;
+  a.rpw = (int)rpw;
+  const unsigned grid = (unsigned)ceil_div(W.rows, rpw * nw);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_regacc_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(spmm_regacc_kernel, dim3(grid), dim3(RA_THREADS), (size_t)W.KC * 256, ctx().stream, a);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
 // ============================================================== transpose (layout conversion)
 // in: rows x cols, element (r,c) at in[r*ldin + c]; out: (c,r) at out[c*ldout + r]
 template <class T>

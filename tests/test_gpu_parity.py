@@ -354,7 +354,7 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
     for B in (1, 2, 5, 16):       # LDS-chunked narrow kernel, 8 chunks, partial sums combined in order
         assert_close(w.spmm(R[:, :B].copy()), W @ R[:, :B], np.float64)
     w32 = ss.DeviceSpMat(W, dtype=np.float32)
-    for B in (1, 4, 9):
+    for B in (1, 4, 9, 17, 40, 64):   # 17..64: register-accumulator kernel, 8 LDS chunks of R
         assert_close(w32.spmm(R[:, :B].astype(np.float32)), W @ R[:, :B], np.float32)
     monkeypatch.setenv("SS_NARROW_CSR", "1")   # the L2-gather CSR kernel (what 16 < B <= 64 uses)
     assert_close(w.spmm(R[:, :5].copy()), W @ R[:, :5], np.float64)
