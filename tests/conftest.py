@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build them once (hipcc cross-compiles for
+    gfx950 without a GPU; gcc builds the CPU checker)."""
+    lib = os.path.join(ROOT, "simspread.jl_amd", "libsimspread_hip.so")
+    ora = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(ora)):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "simspread.jl_amd", "csrc"), "-j4"], check=True,
+                       stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+
+
 def _has_gpu():
     try:
         import torch
