@@ -24,7 +24,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3    # fp32 vector == fp32-input MFMA peak
 
 
-def synth_c2(nq, ns, nf, nt, dx, dy, seed, rank):
+def synth_c2(nq, ns, nf, nt, dx, dy, seed, rank, weighted=True):
     """Seeded C2-shaped inputs.  The graph (Xs, Ys) is the same on every rank, the
     query block differs per rank."""
     import scipy.sparse as sp
@@ -37,12 +37,12 @@ def synth_c2(nq, ns, nf, nt, dx, dy, seed, rank):
         m.sort_indices()
         return m
 
-    Xs = rand_csr(rng_g, ns, nf, dx, True).tolil()
+    Xs = rand_csr(rng_g, ns, nf, dx, weighted).tolil()
     Xs.setdiag(1.0)
     Xs = Xs.tocsr().astype(np.float32)
     Xs.sort_indices()
     Ys = rand_csr(rng_g, ns, nt, dy, False)
-    Xq = rand_csr(rng_q, nq, nf, dx, True)
+    Xq = rand_csr(rng_q, nq, nf, dx, weighted)
     return Xq, Xs, Ys
 
 
@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--n", type=int, default=10_000, help="sources = features = targets")
     ap.add_argument("--dx", type=float, default=0.05)
     ap.add_argument("--dy", type=float, default=0.01)
+    ap.add_argument("--unweighted", action="store_true", help="binary similarity features (featurize(..., weighted=false))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the score blocks (outside `value`)")
@@ -147,7 +148,7 @@ def main():
     ss.use_torch_stream()  # device buffers come from torch: share its stream
 
     nq, n = args.nq, args.n
-    Xq, Xs, Ys = synth_c2(nq, n, n, n, args.dx, args.dy, seed=20250222 + 2, rank=rank)
+    Xq, Xs, Ys = synth_c2(nq, n, n, n, args.dx, args.dy, seed=20250222 + 2, rank=rank, weighted=not args.unweighted)
     g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
     scores = torch.empty((nq, n), dtype=torch.float32, device="cuda")
 
@@ -225,8 +226,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d queries x %d targets per GPU, %d sources/features, "
-                                   "%.0f%% similarity, %.0f%% bipartite density, fp32, full predict()"
-                                   % (nq, n, n, args.dx * 100, args.dy * 100),
+                                   "%.0f%% similarity (%s), %.0f%% bipartite density, fp32, full predict()"
+                                   % (nq, n, n, args.dx * 100, "unweighted" if args.unweighted else "weighted U(0.5,1]",
+                                      args.dy * 100),
                        "queries_per_gpu": nq, "sources": n, "features": n, "targets": n,
                        "nnz_Xq": g.nnz_xq, "nnz_Xs": g.nnz_xs, "nnz_Ys": g.nnz_ys, "sharding": "query rows, no collective"},
             "roofline": roofline,

@@ -761,6 +761,7 @@ int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out) {
   out.nnz = in.nnz;
   out.SC = SC;
   out.align = align;
+  out.binary = in.binary;
   out.nchunks = (int)(in.cols > 0 ? ceil_div(in.cols, SC) : 1);
   const int64_t total = in.rows * out.nchunks;
   SS_TRY(out.off.alloc(total + 1));

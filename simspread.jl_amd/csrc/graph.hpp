@@ -51,6 +51,7 @@ template <class T>
 struct DevChunked {
   int64_t rows = 0, cols = 0, nnz = 0;
   int64_t stored = 0;          // entries incl. padding
+  bool binary = false;         // every stored value == 1 (unweighted features): kernels may skip the value stream
   int SC = 0, nchunks = 0;
   int align = 1;               // sub-rows padded to whole units of `align` entries; off[] counts units.
                                // Padding entries carry local index SC (a zero operand row) and value 0.

@@ -166,7 +166,7 @@ struct SubRows {
   T v2[U];
 };
 
-template <class T, int U>
+template <class T, int U, bool BINM>
 __device__ __forceinline__ void subrows_load(SubRows<T, U>& s, int first, int b_l, int n_l, T cf_l,
                                              const unsigned short* __restrict__ midx, const T* __restrict__ mval,
                                              int lane) {
@@ -179,13 +179,13 @@ __device__ __forceinline__ void subrows_load(SubRows<T, U>& s, int first, int b_
     const unsigned short* pi = midx + s.b[u];
     const T* pv = mval + s.b[u];
     s.j[u] = pi[lane];
-    s.v[u] = pv[lane];
+    s.v[u] = BINM ? T(1) : pv[lane];  // unweighted features: every stored value is 1, two thirds of the bytes vanish
     // With the chunk sized for a mean sub-row of ~60 entries, ~40 % of the sub-rows are longer than one
     // wave: their second half must be prefetched like the first (a dependent load inside the fold
     // stalls the whole batch), so it is issued here under a wave-uniform branch.
     if (s.n[u] > 64) {
       s.j2[u] = pi[64 + lane];
-      s.v2[u] = pv[64 + lane];
+      s.v2[u] = BINM ? T(1) : pv[64 + lane];
     }
   }
 }
@@ -220,7 +220,7 @@ __device__ __forceinline__ void subrows_fold(const SubRows<T, U>& s, int first, 
   }
 }
 
-template <class T, bool LOO, int U>
+template <class T, bool LOO, int U, bool BINM>
 __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs<T> p) {
   static_assert(64 % (2 * U) == 0, "U must divide 32");
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -265,12 +265,12 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
       const int cnt = __builtin_amdgcn_readfirstlane((le - g0 < 64) ? (le - g0) : 64);
       // ---- fold the sub-rows in, U at a time; the loads of the next U are in flight meanwhile
       SubRows<T, U> A, B;
-      subrows_load<T, U>(A, 0, b_l, n_l, cf_l, midx, mval, lane);
+      subrows_load<T, U, BINM>(A, 0, b_l, n_l, cf_l, midx, mval, lane);
       for (int u0 = 0; u0 < cnt; u0 += 2 * U) {
-        if (u0 + U < cnt) subrows_load<T, U>(B, u0 + U, b_l, n_l, cf_l, midx, mval, lane);
+        if (u0 + U < cnt) subrows_load<T, U, BINM>(B, u0 + U, b_l, n_l, cf_l, midx, mval, lane);
         subrows_fold<T, U>(A, u0, b_l, n_l, cf_l, acc, dummy, midx, mval, lane);
         if (u0 + U < cnt) {
-          if (u0 + 2 * U < cnt) subrows_load<T, U>(A, u0 + 2 * U, b_l, n_l, cf_l, midx, mval, lane);
+          if (u0 + 2 * U < cnt) subrows_load<T, U, BINM>(A, u0 + 2 * U, b_l, n_l, cf_l, midx, mval, lane);
           subrows_fold<T, U>(B, u0 + U, b_l, n_l, cf_l, acc, dummy, midx, mval, lane);
         }
       }
@@ -325,8 +325,14 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
   const size_t lds = (size_t)(p.SC + 64) * sizeof(T);
-  hipLaunchKernelGGL((transfer_kernel<T, false, TRANSFER_U>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
-                     ctx().stream, p);
+  bool binm = true;
+  for (int t = 0; t < nterms; ++t) binm = binm && Mt[t]->binary;
+  if (binm)
+    hipLaunchKernelGGL((transfer_kernel<T, false, TRANSFER_U, true>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
+                       ctx().stream, p);
+  else
+    hipLaunchKernelGGL((transfer_kernel<T, false, TRANSFER_U, false>), dim3((unsigned)grid), dim3(TRANSFER_THREADS),
+                       lds, ctx().stream, p);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
@@ -350,8 +356,12 @@ int launch_transfer_loo(const DevCsr<T>& X, const DevChunked<T>& XT, const int* 
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
   const size_t lds = (size_t)(p.SC + 64) * sizeof(T) + (size_t)((p.SC + 31) / 32) * 4;
-  hipLaunchKernelGGL((transfer_kernel<T, true, TRANSFER_U>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
-                     ctx().stream, p);
+  if (XT.binary)
+    hipLaunchKernelGGL((transfer_kernel<T, true, TRANSFER_U, true>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
+                       ctx().stream, p);
+  else
+    hipLaunchKernelGGL((transfer_kernel<T, true, TRANSFER_U, false>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
+                       ctx().stream, p);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }

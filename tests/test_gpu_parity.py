@@ -185,6 +185,19 @@ def test_dense_assembly_with_fused_cutoff_matches_featurize(dtype):
         assert_close(g.predict("query"), O.predict_factored(Xq, Xs, Y.astype(np.float64)), dtype)
 
 
+def test_results_are_bitwise_reproducible():
+    # no float atomics anywhere: every sum has a fixed order, so repeated runs and fresh handles agree bit for bit
+    Xq, Xs, Ys = O.synth_bipartite(300, 2000, 2000, 900, 0.05, 0.02, seed=31, dtype=np.float32)
+    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    a = g.predict("query").copy()
+    for _ in range(3):
+        assert np.array_equal(g.predict("query"), a)
+    g2 = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    assert np.array_equal(g2.predict("query"), a)
+    s = g.predict("source").copy()
+    assert np.array_equal(g2.predict("source"), s)
+
+
 def test_multi_chunk_and_row_batches(monkeypatch):
     # force several LDS chunks of W's columns and several transfer batches; results must not change
     Xq, Xs, Ys = O.synth_bipartite(150, 700, 700, 300, 0.05, 0.03, seed=9, dtype=np.float32)
