@@ -559,7 +559,14 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   }
   hipEvent_t e_begin, e_end;
   SS_TRY(timing_mark(&e_begin));
-  const bool narrow = (B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR);
+  // row-major operands: B <= 8 streams W once with R chunks in LDS (HBM-bound kernel); 8 < B <= 64 goes, by
+  // default, to the wide LDS-tiled kernel with the slices split over workgroups (W is then streamed B/4 times:
+  // measured at 100k x 100k / 1 %: B=16 0.55 ms vs 0.71 ms, B=64 1.18 ms vs 4.9 ms for the register-accumulator
+  // kernel (SS_NARROW_REGACC=1) and 5.6 ms for gathering rows of R from L2 (SS_NARROW_CSR=1))
+  int wide_from = 9;
+  if (const char* e = getenv("SS_WIDE_FROM")) wide_from = atoi(e);
+  const bool wide_for_mid = (B >= wide_from && getenv("SS_NARROW_REGACC") == nullptr && getenv("SS_NARROW_CSR") == nullptr);
+  const bool narrow = (B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR && !wide_for_mid);
   DevBuf<T> Rt, Ft;
   const bool use_csr_gather = getenv("SS_NARROW_CSR") != nullptr;
   if (narrow && B <= 16 && !use_csr_gather) {

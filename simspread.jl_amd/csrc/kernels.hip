@@ -430,7 +430,8 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
 
     const int* off = a.off + (int64_t)c * a.nslices;
     const bool last = (c == a.nchunks - 1);
-    for (int s = wave; s < a.nslices; s += nwaves) {
+    // few tiles (narrow R): the slices are also split over gridDim.y workgroups per tile
+    for (int s = wave + nwaves * (int)blockIdx.y; s < a.nslices; s += nwaves * (int)gridDim.y) {
       const int o = __builtin_amdgcn_readfirstlane(off[s]);
       const int oe = __builtin_amdgcn_readfirstlane(off[s + 1]);
       T acc[QT];
@@ -540,7 +541,14 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
   a.ldf = ldf;
   a.clean_deg = clean_deg;
   const size_t lds = (size_t)(W.KC + 1) * QT * sizeof(T);
-  const unsigned grid = (unsigned)ceil_div(B, QT);
+  const unsigned gx = (unsigned)ceil_div(B, QT);
+  unsigned gy = 1;
+  if ((int)gx < 2 * ctx().num_cu) {
+    gy = (unsigned)ceil_div(2 * ctx().num_cu, (int64_t)gx);
+    const unsigned maxy = (unsigned)ceil_div(W.nslices, SELL_THREADS / 64);
+    if (gy > maxy) gy = maxy > 0 ? maxy : 1;
+  }
+  const dim3 grid(gx, gy);
   static bool attr_set[2] = {false, false};
   if (W.binary) {
     if (!attr_set[0]) {
@@ -548,14 +556,14 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set[0] = true;
     }
-    hipLaunchKernelGGL((spmm_sell_kernel<T, QT, true>), dim3(grid), dim3(SELL_THREADS), lds, ctx().stream, a);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, QT, true>), grid, dim3(SELL_THREADS), lds, ctx().stream, a);
   } else {
     if (!attr_set[1]) {
       SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set[1] = true;
     }
-    hipLaunchKernelGGL((spmm_sell_kernel<T, QT, false>), dim3(grid), dim3(SELL_THREADS), lds, ctx().stream, a);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, QT, false>), grid, dim3(SELL_THREADS), lds, ctx().stream, a);
   }
   SS_LAUNCH_CHECK();
   return SS_OK;
