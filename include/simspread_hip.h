@@ -178,6 +178,17 @@ int ss_predict_loo_f32(ss_graph* g, int64_t i_begin, int64_t i_end, int clean,
 int ss_predict_loo_f64(ss_graph* g, int64_t i_begin, int64_t i_end, int clean,
                        double* out, int64_t ld, int layout, int mem);
 
+/* k-fold cross-validation in one call: fold_of_source[i] in [0, nfolds) for every source i; row i of the
+ * result is what the reference's fold loop computes for source i when its fold is the query set,
+ *   predict(construct(y, X, fold_members), y[fold_members, :])  (+ clean!)   (src/core.jl:148-201,402-423),
+ * i.e. the members of a fold are removed from the sources AND their feature columns are dropped
+ * (src/core.jl:152-153), degrees recounted.  Needs a graph with nq == 0 and ns == nf whose feature column j
+ * is the one named after source j.  out is ns x nt.  With one source per fold this equals leave-one-out. */
+int ss_predict_kfold_f32(ss_graph* g, const int32_t* fold_of_source, int nfolds, int clean,
+                         float* out, int64_t ld, int layout, int mem);
+int ss_predict_kfold_f64(ss_graph* g, const int32_t* fold_of_source, int nfolds, int clean,
+                         double* out, int64_t ld, int layout, int mem);
+
 /* -------------------------------------------------------------- raw W*R SpMM --- */
 /* The resource-spreading product F = W * R on its own (kernel unit tests and the
  * roofline benchmark; inside predict W = Ys' and R = the transfer block, src/core.jl:413).

@@ -156,6 +156,28 @@ function predict_loo(g::Graph{T}; clean::Bool=true, range=nothing) where {T}
     return Matrix{Float64}(out)
 end
 
+"""
+    predict_kfold(g, fold_of_source; clean=true)
+
+k-fold cross-validation in one call (`fold_of_source[i] ∈ 1:k`, e.g. from `split`): row `i` is what the fold loop
+`construct(y, X, members)` + `predict` (+ `clean!`) gives for source `i` when its fold is held out.
+"""
+function predict_kfold(g::Graph{T}, fold_of_source::AbstractVector{<:Integer}; clean::Bool=true) where {T}
+    length(fold_of_source) == g.ns || throw(AssertionError("one fold index per source is needed"))
+    folds = Vector{Int32}(fold_of_source .- 1)
+    k = Int(maximum(folds)) + 1
+    out = Matrix{T}(undef, g.ns, g.nt)
+    rc = if T === Float32
+        ccall((:ss_predict_kfold_f32, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Cint, Cint, Ptr{Float32}, Int64, Cint, Cint),
+              g.handle, folds, k, clean ? 1 : 0, out, max(g.ns, 1), SS_LAYOUT_COLMAJOR, SS_MEM_HOST)
+    else
+        ccall((:ss_predict_kfold_f64, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Cint, Cint, Ptr{Float64}, Int64, Cint, Cint),
+              g.handle, folds, k, clean ? 1 : 0, out, max(g.ns, 1), SS_LAYOUT_COLMAJOR, SS_MEM_HOST)
+    end
+    check(rc)
+    return Matrix{Float64}(out)
+end
+
 "cutoff(X, alpha, weighted) on the device (src/core.jl:55-60)."
 function cutoff(X::Matrix{Float64}, alpha::Float64, weighted::Bool=false)
     out = similar(X)

@@ -63,6 +63,7 @@ def _sigs():
         s[f"ss_graph_create_general_{suf}"] = ([_i64] * 3 + [_vp] * 9 + [_int, _int, _vp], _int)
         s[f"ss_predict_{suf}"] = ([_vp, _int, _i64, _i64, _int, _vp, _i64, _int, _int], _int)
         s[f"ss_predict_loo_{suf}"] = ([_vp, _i64, _i64, _int, _vp, _i64, _int, _int], _int)
+        s[f"ss_predict_kfold_{suf}"] = ([_vp, _vp, _int, _int, _vp, _i64, _int, _int], _int)
         s[f"ss_spmat_create_csr_{suf}"] = ([_i64, _i64, _vp, _vp, _vp, _int, _int, _vp], _int)
         s[f"ss_spmm_{suf}"] = ([_vp, _vp, _i64, _i64, _int, _vp, _i64, _int, _int], _int)
     return s

@@ -493,6 +493,131 @@ static int predict_impl(ss_graph* h, int kind, int64_t row_begin, int64_t row_en
   return SS_OK;
 }
 
+// k-fold: all folds of construct(y, X, members) + predict (+ clean!) from the resident graph
+template <class T>
+static int predict_kfold_impl(ss_graph* h, const int32_t* fold_of_source, int nfolds, int clean, T* out, int64_t ld,
+                              int layout, int mem) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  SS_TRY(check_layout(layout));
+  Graph<T>* gp = nullptr;
+  SS_TRY(graph_check<T>(h, &gp));
+  Graph<T>& g = *gp;
+  if (g.general || g.dense.on || g.nq != 0 || g.ns != g.nf)
+    return fail(SS_EINVAL, "k-fold needs a sparse graph with nq == 0 and ns == nf (feature j named after source j)");
+  if (nfolds < 1 || !fold_of_source) return fail(SS_EINVAL, "k-fold: bad fold assignment");
+  const int64_t ns = g.ns, nt = g.nt;
+  if (ns == 0 || nt == 0) return SS_OK;
+  if (!out) return fail(SS_EINVAL, "output buffer is NULL");
+  const int64_t need_ld = (layout == SS_LAYOUT_ROWMAJOR) ? nt : ns;
+  if (ld < need_ld) return fail(SS_EINVAL, "leading dimension %lld < %lld", (long long)ld, (long long)need_ld);
+  hipStream_t st = ctx().stream;
+  // members of each fold, in source order (stable counting sort on the host)
+  std::vector<int32_t> fold(ns);
+  if (mem == SS_MEM_HOST) memcpy(fold.data(), fold_of_source, ns * sizeof(int32_t));
+  else SS_HIP(hipMemcpy(fold.data(), fold_of_source, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::vector<int> start(nfolds + 1, 0), order(ns);
+  for (int64_t i = 0; i < ns; ++i) {
+    if (fold[i] < 0 || fold[i] >= nfolds) return fail(SS_EINVAL, "fold_of_source[%lld] = %d outside 0..%d", (long long)i, fold[i], nfolds - 1);
+    start[fold[i] + 1]++;
+  }
+  for (int f = 0; f < nfolds; ++f) start[f + 1] += start[f];
+  {
+    std::vector<int> cur(start.begin(), start.end() - 1);
+    for (int64_t i = 0; i < ns; ++i) order[cur[fold[i]]++] = (int)i;
+  }
+  DevBuf<int> d_fold, d_order, kf, ks, kt;
+  DevBuf<T> inv_kf, inv_ks;
+  SS_TRY(d_fold.alloc(ns)); SS_TRY(d_order.alloc(ns));
+  SS_TRY(kf.alloc(g.nf)); SS_TRY(ks.alloc(ns)); SS_TRY(kt.alloc(nt));
+  SS_TRY(inv_kf.alloc(g.nf)); SS_TRY(inv_ks.alloc(ns));
+  SS_HIP(hipMemcpyAsync(d_fold.p, fold.data(), ns * sizeof(int), hipMemcpyHostToDevice, st));
+  SS_HIP(hipMemcpyAsync(d_order.p, order.data(), ns * sizeof(int), hipMemcpyHostToDevice, st));
+  SS_TRY(graph_sell(g));
+  SS_TRY(graph_chunked(g, false));
+
+  timing_begin_call();
+  hipEvent_t e_begin, e_end;
+  SS_TRY(timing_mark(&e_begin));
+  const bool direct = (mem == SS_MEM_DEVICE && layout == SS_LAYOUT_ROWMAJOR);
+  DevBuf<T> scores;
+  T* dev_rm = out;
+  int64_t ld_rm = ld;
+  if (!direct) {
+    SS_TRY(scores.alloc((size_t)ns * nt));
+    dev_rm = scores.p;
+    ld_rm = nt;
+  }
+  DevBuf<T> sorted_tmp;
+  for (int phi = 0; phi < nfolds; ++phi) {
+    const int64_t nm = start[phi + 1] - start[phi];
+    if (nm == 0) continue;
+    const int* members = d_order.p + start[phi];
+    SS_HIP(hipMemcpyAsync(kf.p, g.kf.p, g.nf * sizeof(int), hipMemcpyDeviceToDevice, st));
+    SS_HIP(hipMemcpyAsync(ks.p, g.ks.p, ns * sizeof(int), hipMemcpyDeviceToDevice, st));
+    SS_HIP(hipMemcpyAsync(kt.p, g.kt.p, nt * sizeof(int), hipMemcpyDeviceToDevice, st));
+    SS_TRY(launch_fold_degrees<T>(g.Xs, g.XsT, g.Ys, members, nm, kf.p, ks.p, kt.p));
+    SS_TRY(launch_fold_inverse<T>(kf.p, ks.p, d_fold.p, phi, g.nf, ns, inv_kf.p, inv_ks.p));
+    const int64_t rb = transfer_batch_rows(nm, ns, sizeof(T));
+    const size_t need = (size_t)rb * (size_t)ns;
+    if (g.Tws.n < need) SS_TRY(g.Tws.alloc(need));
+    for (int64_t r0 = 0; r0 < nm; r0 += rb) {
+      const int64_t nb = (nm - r0 < rb) ? (nm - r0) : rb;
+      {
+        StageTimer t1(ST_TRANSFER);
+        const DevCsr<T>* L[2] = {&g.Xs, nullptr};
+        const DevChunked<T>* M[2] = {&g.XsTc, nullptr};
+        const T* inv1[2] = {inv_kf.p, nullptr};
+        SS_TRY(launch_transfer<T>(1, L, inv1, M, inv_ks.p, r0, nb, ns, g.Tws.p, ns, members));
+        timing_count(ST_NTRANSFER, 1);
+      }
+      if (!g.W.sorted) {
+        StageTimer t2(ST_SPMM);
+        SS_TRY(launch_spmm_sell<T>(g.W, g.Tws.p, ns, nb, dev_rm, ld_rm, clean ? kt.p : nullptr, members + r0));
+        timing_count(ST_NSPMM, 1);
+      } else {
+        const size_t need_s = (size_t)rb * (size_t)g.W.vrows + (size_t)rb * (size_t)nt;
+        if (g.Sws.n < need_s) SS_TRY(g.Sws.alloc(need_s));
+        T* packed = g.Sws.p + (size_t)rb * (size_t)g.W.vrows;  // member-ordered rows before the scatter
+        {
+          StageTimer t2(ST_SPMM);
+          SS_TRY(launch_spmm_sell<T>(g.W, g.Tws.p, ns, nb, g.Sws.p, g.W.vrows, nullptr));
+          timing_count(ST_NSPMM, 1);
+        }
+        StageTimer t3(ST_EPILOGUE);
+        SS_TRY(launch_unpermute<T>(g.Sws.p, g.W.vrows, nb, nt, g.W.vfirst.p, g.W.inv.p, clean ? kt.p : nullptr, packed, nt));
+        for (int64_t q = 0; q < nb; ++q)  // few folds x rows: row copies to the members' source rows
+          SS_HIP(hipMemcpyAsync(dev_rm + (int64_t)order[start[phi] + r0 + q] * ld_rm, packed + q * nt, nt * sizeof(T),
+                                hipMemcpyDeviceToDevice, st));
+      }
+    }
+  }
+  DevBuf<T> cm;
+  if (layout == SS_LAYOUT_COLMAJOR) {
+    StageTimer t3(ST_EPILOGUE);
+    T* dst = out;
+    int64_t dld = ld;
+    if (mem == SS_MEM_HOST) {
+      SS_TRY(cm.alloc((size_t)ns * nt));
+      dst = cm.p;
+      dld = ns;
+    }
+    SS_TRY(launch_transpose<T>(dev_rm, ns, nt, ld_rm, dst, dld));
+  }
+  SS_TRY(timing_mark(&e_end));
+  timing_span(ST_TOTAL, e_begin, e_end);
+  if (mem == SS_MEM_HOST) {
+    StageTimer t5(ST_D2H);
+    if (layout == SS_LAYOUT_ROWMAJOR)
+      SS_HIP(hipMemcpy2DAsync(out, ld * sizeof(T), dev_rm, ld_rm * sizeof(T), nt * sizeof(T), ns, hipMemcpyDeviceToHost, st));
+    else
+      SS_HIP(hipMemcpy2DAsync(out, ld * sizeof(T), cm.p, ns * sizeof(T), ns * sizeof(T), nt, hipMemcpyDeviceToHost, st));
+    t5.stop();
+  }
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
 // ------------------------------------------------------------------ raw SpMM
 template <class T>
 static int spmat_check(const void* h, SpMat<T>** out) {
@@ -893,6 +1018,15 @@ int ss_predict_loo_f32(ss_graph* g, int64_t i_begin, int64_t i_end, int clean, f
 int ss_predict_loo_f64(ss_graph* g, int64_t i_begin, int64_t i_end, int clean, double* out, int64_t ld, int layout,
                        int mem) {
   return predict_impl<double>(g, 2, i_begin, i_end, clean, out, ld, layout, mem);
+}
+
+int ss_predict_kfold_f32(ss_graph* g, const int32_t* fold_of_source, int nfolds, int clean, float* out, int64_t ld,
+                         int layout, int mem) {
+  return predict_kfold_impl<float>(g, fold_of_source, nfolds, clean, out, ld, layout, mem);
+}
+int ss_predict_kfold_f64(ss_graph* g, const int32_t* fold_of_source, int nfolds, int clean, double* out, int64_t ld,
+                         int layout, int mem) {
+  return predict_kfold_impl<double>(g, fold_of_source, nfolds, clean, out, ld, layout, mem);
 }
 
 int ss_spmat_create_csr_f32(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const float* val,

@@ -152,7 +152,15 @@ int launch_spread_dense(const T* G, int64_t rows, int64_t cols, int64_t ld, cons
 // all Mt operands must share SC / nchunks
 template <class T>
 int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
-                    const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld);
+                    const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld,
+                    const int* row_ids = nullptr);
+// k-fold: degrees / reciprocal degrees of the graph without the members of one fold
+template <class T>
+int launch_fold_degrees(const DevCsr<T>& X, const DevCsr<T>& XT, const DevCsr<T>& Y, const int* members,
+                        int64_t nmembers, int* kf, int* ks, int* kt);
+template <class T>
+int launch_fold_inverse(const int* kf, const int* ks, const int* fold, int phi, int64_t nf, int64_t ns, T* inv_kf,
+                        T* inv_ks);
 // leave-one-out flavour: row i of X against X' with the rank-1 degree corrections
 template <class T>
 int launch_transfer_loo(const DevCsr<T>& X, const DevChunked<T>& XT, const int* kf, const int* ks,
@@ -165,7 +173,7 @@ template <class T>
 int sell_max_chunk(int qt);
 template <class T>
 int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T* F, int64_t ldf,
-                     const int* clean_deg);
+                     const int* clean_deg, const int* out_rows = nullptr);
 // stage 2, narrow (B <= 16): R chunk in LDS, W streamed once from HBM in chunk-major order
 template <class T>
 int narrow_chunk_cols(int bv);  // KC for a padded width bv

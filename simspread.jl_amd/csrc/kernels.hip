@@ -118,6 +118,7 @@ struct TransferArgs {
   const int* kf;  // LOO: integer degrees
   const int* ks;
   int64_t row_begin;
+  const int* row_ids;  // optional: row of L handled by workgroup-row r is row_ids[row_begin + r] (k-fold members)
   int64_t nj;
   int SC;       // columns of T per workgroup (= chunk of the Mt operands)
   int nchunks;
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
   const int lane = threadIdx.x;
   const int c = blockIdx.x % p.nchunks;
   const int64_t r = blockIdx.x / p.nchunks;
-  const int64_t gr = p.row_begin + r;
+  const int64_t gr = p.row_ids ? (int64_t)p.row_ids[p.row_begin + r] : p.row_begin + r;
   const int64_t j0 = (int64_t)c * p.SC;
   const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
   const int dummy = p.SC + lane;
@@ -304,7 +305,8 @@ constexpr int TRANSFER_U = 8;
 
 template <class T>
 int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
-                    const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld) {
+                    const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld,
+                    const int* row_ids) {
   if (nrows <= 0 || nj <= 0) return SS_OK;
   TransferArgs<T> p{};
   p.nterms = nterms;
@@ -317,6 +319,7 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
   }
   p.inv2 = inv2;
   p.row_begin = row_begin;
+  p.row_ids = row_ids;
   p.nj = nj;
   p.SC = Mt[0]->SC;
   p.nchunks = Mt[0]->nchunks;
@@ -384,6 +387,7 @@ struct SellArgs {
   T* F;
   int64_t ldf;
   const int* clean_deg;
+  const int* out_rows;  // optional: column b of R goes to row out_rows[b] of F (k-fold members -> source rows)
 };
 
 constexpr int SELL_THREADS = 1024;
@@ -498,7 +502,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
           if (b0 + q < a.B) {
-            T* f = a.F + (b0 + q) * a.ldf + m;
+            T* f = a.F + (a.out_rows ? (int64_t)a.out_rows[b0 + q] : b0 + q) * a.ldf + m;
             T r = acc[q];
             if (c) r += *f;
             *f = flag ? T(-99) : r;
@@ -522,7 +526,7 @@ int sell_max_chunk(int qt) {
 
 template <class T>
 int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T* F, int64_t ldf,
-                     const int* clean_deg) {
+                     const int* clean_deg, const int* out_rows) {
   if (B <= 0 || W.rows <= 0) return SS_OK;
   constexpr int QT = sizeof(T) == 4 ? 4 : 2;
   SellArgs<T> a{};
@@ -540,6 +544,7 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
   a.F = F;
   a.ldf = ldf;
   a.clean_deg = clean_deg;
+  a.out_rows = out_rows;
   const size_t lds = (size_t)(W.KC + 1) * QT * sizeof(T);
   const unsigned gx = (unsigned)ceil_div(B, QT);
   unsigned gy = 1;
@@ -1081,6 +1086,60 @@ int launch_unpermute(const T* in, int64_t ldin, int64_t nrows, int64_t nt, const
   return SS_OK;
 }
 
+// ============================================================== k-fold: degrees of the graph without a fold's members
+// construct(y, X, queries) (src/core.jl:148-201) drops the query rows from the sources and the feature
+// columns named after them: kf[f] loses one per member row with X[g,f] != 0, ks[s] one per member feature
+// column with X[s,g] != 0, kt[t] one per member with Y[g,t] != 0.  One wave per member; integer atomics.
+__global__ void fold_degrees_kernel(const int* __restrict__ xptr, const int* __restrict__ xidx,
+                                    const int* __restrict__ tptr, const int* __restrict__ tidx,
+                                    const int* __restrict__ yptr, const int* __restrict__ yidx,
+                                    const int* __restrict__ members, int64_t nmembers, int* __restrict__ kf,
+                                    int* __restrict__ ks, int* __restrict__ kt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t m = wave0; m < nmembers; m += nwaves) {
+    const int g = members[m];
+    for (int x = xptr[g] + lane; x < xptr[g + 1]; x += 64) atomicSub(&kf[xidx[x]], 1);
+    for (int x = tptr[g] + lane; x < tptr[g + 1]; x += 64) atomicSub(&ks[tidx[x]], 1);
+    for (int x = yptr[g] + lane; x < yptr[g + 1]; x += 64) atomicSub(&kt[yidx[x]], 1);
+  }
+}
+
+template <class T>
+int launch_fold_degrees(const DevCsr<T>& X, const DevCsr<T>& XT, const DevCsr<T>& Y, const int* members,
+                        int64_t nmembers, int* kf, int* ks, int* kt) {
+  if (nmembers <= 0) return SS_OK;
+  hipLaunchKernelGGL(fold_degrees_kernel, dim3(grid_1d(nmembers * 64, 256)), dim3(256), 0, ctx().stream, X.ptr.p,
+                     X.idx.p, XT.ptr.p, XT.idx.p, Y.ptr.p, Y.idx.p, members, nmembers, kf, ks, kt);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// reciprocal degrees of the fold's graph; members are neither features nor sources in it (-> 0)
+template <class T>
+__global__ void fold_inverse_kernel(const int* __restrict__ kf, const int* __restrict__ ks,
+                                    const int* __restrict__ fold, int phi, int64_t nf, int64_t ns,
+                                    T* __restrict__ inv_kf, T* __restrict__ inv_ks) {
+  const int64_t n = nf > ns ? nf : ns;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool member = fold[i] == phi;
+    if (i < nf) inv_kf[i] = (!member && kf[i] > 0) ? T(1) / T(kf[i]) : T(0);
+    if (i < ns) inv_ks[i] = (!member && ks[i] > 0) ? T(1) / T(ks[i]) : T(0);
+  }
+}
+
+template <class T>
+int launch_fold_inverse(const int* kf, const int* ks, const int* fold, int phi, int64_t nf, int64_t ns, T* inv_kf,
+                        T* inv_ks) {
+  const int64_t n = nf > ns ? nf : ns;
+  if (n <= 0) return SS_OK;
+  hipLaunchKernelGGL(fold_inverse_kernel<T>, dim3(grid_1d(n, 256)), dim3(256), 0, ctx().stream, kf, ks, fold, phi, nf,
+                     ns, inv_kf, inv_ks);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
 // ============================================================== LOO clean! fix-up
 // In fold i target t has degree kt[t] - [Y[i,t] != 0] (src/core.jl:479): the kt == 0 columns are
 // flagged by the SpMM epilogue, here the columns whose single edge belongs to the query itself.
@@ -1111,11 +1170,15 @@ int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, i
   template int launch_row_degree<T>(const T*, int64_t, int64_t, int64_t, int*);                             \
   template int launch_spread_dense<T>(const T*, int64_t, int64_t, int64_t, const int*, T*, int64_t);        \
   template int launch_transfer<T>(int, const DevCsr<T>*[2], const T*[2], const DevChunked<T>*[2], const T*, \
-                                  int64_t, int64_t, int64_t, T*, int64_t);                                  \
+                                  int64_t, int64_t, int64_t, T*, int64_t, const int*);                      \
+  template int launch_fold_degrees<T>(const DevCsr<T>&, const DevCsr<T>&, const DevCsr<T>&, const int*,     \
+                                      int64_t, int*, int*, int*);                                           \
+  template int launch_fold_inverse<T>(const int*, const int*, const int*, int, int64_t, int64_t, T*, T*);   \
   template int launch_transfer_loo<T>(const DevCsr<T>&, const DevChunked<T>&, const int*, const int*,       \
                                       int64_t, int64_t, T*, int64_t);                                                \
   template int sell_max_chunk<T>(int);                                                                      \
-  template int launch_spmm_sell<T>(const DevSell<T>&, const T*, int64_t, int64_t, T*, int64_t, const int*); \
+  template int launch_spmm_sell<T>(const DevSell<T>&, const T*, int64_t, int64_t, T*, int64_t, const int*,  \
+                                   const int*);                                                             \
   template int launch_spmm_csr_narrow<T>(const DevCsr<T>&, const T*, int64_t, int, T*, int64_t);            \
   template int narrow_chunk_cols<T>(int);                                                                   \
   template int launch_spmm_chunked_narrow<T>(const DevChunked<T>&, int, const T*, int64_t, int, T*, int64_t, \

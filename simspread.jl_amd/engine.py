@@ -267,6 +267,19 @@ class DeviceGraph:
         i_end = self.ns if i_end is None else i_end
         return self._run("ss_predict_loo", (i_begin, i_end), i_end - i_begin, clean, out, layout)
 
+    def predict_kfold(self, fold_of_source, nfolds: Optional[int] = None, clean: bool = False):
+        """All folds of a k-fold cross-validation in one call: row i = the scores of source i when its fold is
+        held out (construct(y, X, members) + predict (+ clean!) for every fold).  Returns (ns, nt) numpy."""
+        fold = np.ascontiguousarray(fold_of_source, dtype=np.int32)
+        if fold.shape != (self.ns,):
+            raise ValueError("fold_of_source must have one entry per source")
+        nfolds = int(fold.max()) + 1 if nfolds is None else nfolds
+        out = np.empty((self.ns, self.nt), dtype=self.dtype)
+        fn = getattr(L.lib(), f"ss_predict_kfold_{self._suf}")
+        L.check(fn(self._h, fold.ctypes.data, nfolds, 1 if clean else 0, out.ctypes.data, self.nt,
+                   L.SS_LAYOUT_ROWMAJOR, L.SS_MEM_HOST))
+        return out
+
     def close(self):
         if self._h is not None and self._h.value:
             L.load().ss_graph_destroy(self._h)

@@ -457,3 +457,33 @@ def test_dense_similarity_equals_sparse_path_on_the_same_input():
     a = ss.DeviceGraph.from_similarity(Sq, Ss, sp.csr_matrix(Y), alpha=0.8, weighted=True).predict("query")
     b = ss.DeviceGraph.from_dense(Sq, Ss, Y, alpha=np.float32(0.8), weighted=True, dtype=np.float32).predict("query")
     np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------- k-fold in one call
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_kfold_equals_the_reference_fold_loop(dtype, monkeypatch):
+    rng = np.random.default_rng(21)
+    n, nt, k = 60, 17, 5
+    S = rng.random((n, n)); S = (S + S.T) / 2; np.fill_diagonal(S, 1.0)
+    names = [f"d{i:02d}" for i in range(n)]; tn = [f"t{i}" for i in range(nt)]
+    Xn = O.featurize(O.Named(S, names, names), 0.6, True)
+    Yarr = (rng.random((n, nt)) < 0.2).astype(float)
+    Yarr[:, 3] = 0; Yarr[7, 3] = 1; Yarr[9, 3] = 1   # a target whose only edges are in one fold -> clean!
+    Yn = O.Named(Yarr, names, tn)
+    fold = rng.integers(0, k, size=n).astype(np.int32); fold[7] = fold[9] = 2
+    want = np.zeros((n, nt))
+    for phi in range(k):
+        members = [names[i] for i in range(n) if fold[i] == phi]
+        A, B = O.construct_queries(Yn, Xn, members)
+        yq = Yn.sub(members, tn)
+        yh = O.predict(A, B, yq); O.clean(yh, A, yq)
+        want[[i for i in range(n) if fold[i] == phi]] = yh.array
+    assert (want[7] == -99).any()
+    for force_sorted in ("0", "1"):
+        monkeypatch.setenv("SS_SELL_SORT", force_sorted)
+        g = ss.DeviceGraph.from_dense(None, Xn.array.astype(dtype), Yarr.astype(dtype), dtype=dtype)
+        assert_close(g.predict_kfold(fold, k, clean=True), want, dtype)
+    # one source per fold is leave-one-out
+    monkeypatch.delenv("SS_SELL_SORT")
+    g = ss.DeviceGraph.from_dense(None, Xn.array.astype(dtype), Yarr.astype(dtype), dtype=dtype)
+    assert_close(g.predict_kfold(np.arange(n, dtype=np.int32), n, clean=True), g.predict_loo(clean=True), dtype)
