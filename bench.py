@@ -109,6 +109,65 @@ def spmm_sweep(ss, torch, steps=5):
     return {"workload": f"W 100k x 100k, 1 percent dense (nnz {nnz}), fp32, CSR streamed once from HBM", "results": out}
 
 
+def bench_c3loo(args, ss, torch, dist, world, rank):
+    """BASELINE configs[2]: 100k x 100k, 1 %, leave-one-out; folds are block-sharded over the ranks
+    (ss.shard_range) and each step scores `--folds` consecutive folds of the rank's shard."""
+    from tools.c3_loo import rand_csr, rand_sym_csr
+    n = 100_000
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20250222 + 3)   # every rank builds the same (replicated) graph
+    xp, xi = rand_sym_csr(n, 0.01, gen)
+    yp, yi = rand_csr(n, n, 0.01, gen)
+    xv = (0.5 + 0.5 * torch.rand(xi.numel(), device="cuda", generator=gen)).float()
+    g = ss.DeviceGraph.from_device_csr(0, n, n, n, None, (xp, xi, xv), (yp, yi, None), dtype=np.float32)
+    lo, hi = ss.shard_range(n, rank, world)
+    folds = min(args.folds, hi - lo)
+    out = torch.empty((folds, n), dtype=torch.float32, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pos = lo
+    for _ in range(args.warmup):
+        g.predict_loo(pos, pos + folds, clean=True, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    st = {"transfer_ms": [], "spmm_ms": []}
+    for i in range(args.steps):
+        b = lo + (i * folds) % max(1, (hi - lo) - folds + 1)
+        g.predict_loo(b, b + folds, clean=True, out=out)
+        t = ss.timing_last()
+        st["transfer_ms"].append(t["transfer_ms"]); st["spmm_ms"].append(t["spmm_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else "cpu")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    if rank == 0:
+        spmm_ms = float(np.mean(st["spmm_ms"]))
+        flops = 2.0 * g.nnz_ys * folds
+        by = csr_bytes(g.nnz_ys, n) + n * folds * 4 * 2
+        print(json.dumps({
+            "metric": "predicted edges/sec + achieved HBM GB/s, W*R SpMM", "value": folds * n * world / (elapsed / args.steps),
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 100k x 100k, 1%% density, leave-one-out folds block-sharded over "
+                                   "ranks, %d folds per rank and step" % folds, "nnz_X": g.nnz_xs, "nnz_Y": g.nnz_ys,
+                       "folds_per_s_per_gpu": folds / (elapsed / args.steps)},
+            "roofline": {"kernel": "spmm_sell_kernel<float,4> (stage 2, B = %d folds, 10 LDS chunks of W)" % folds,
+                         "bound": "mfma", "achieved": round(flops / (spmm_ms * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(flops / (spmm_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                         "traffic": None, "avg_launch_ms": round(spmm_ms, 4), "algorithmic_bytes": by,
+                         "frac_hbm": round(by / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "stage1_transfer_ms": round(float(np.mean(st["transfer_ms"])), 4)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +178,10 @@ def main():
     ap.add_argument("--dx", type=float, default=0.05)
     ap.add_argument("--dy", type=float, default=0.01)
     ap.add_argument("--unweighted", action="store_true", help="binary similarity features (featurize(..., weighted=false))")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3loo"],
+                    help="c2: BASELINE configs[1] (default, the metric's config); c3loo: configs[2], 100k x 100k 1%% "
+                         "leave-one-out, each rank scores --folds consecutive folds of its shard per step")
+    ap.add_argument("--folds", type=int, default=2048, help="c3loo: folds per rank and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the score blocks (outside `value`)")
@@ -147,6 +210,9 @@ def main():
     import simspread_jl_amd as ss
     ss.init(local_rank)
     ss.use_torch_stream()  # device buffers come from torch: share its stream
+
+    if args.workload == "c3loo":
+        return bench_c3loo(args, ss, torch, dist, world, rank)
 
     nq, n = args.nq, args.n
     Xq, Xs, Ys = synth_c2(nq, n, n, n, args.dx, args.dy, seed=20250222 + 2, rank=rank, weighted=not args.unweighted)
