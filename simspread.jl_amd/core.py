@@ -394,3 +394,35 @@ def save(filepath: str, *args, delimiter: str = "\t") -> None:
                 row = [str(pos if fidx is None else fidx), f'"{q}"', f'"{t}"',
                        show(yhat, yhat.array[qi[q], ti[t]]), show(y, y.array[yq[q], yt[t]])]
                 f.write(delimiter.join(row) + "\n")
+
+
+# --------------------------------------------------------------------------- ranked metrics
+def _per_group_hits(y, yhat, grouping, L: int):
+    from .engine import topl
+    y = np.asarray(y, dtype=np.float64).ravel()
+    yhat = np.asarray(yhat, dtype=np.float32).ravel()
+    grouping = np.asarray(grouping).ravel()
+    if not (len(y) == len(yhat) == len(grouping)):
+        raise AssertionError("Number of predictions must match number of labels")
+    if L <= 0:
+        raise AssertionError("Please use a list length greater than 0 (L > 0)")
+    out = []
+    for gname in dict.fromkeys(grouping.tolist()):       # unique(), first-seen order
+        sel = grouping == gname
+        yg, sg = y[sel], yhat[sel]
+        if len(yg) <= L:
+            raise AssertionError("Number of labels is less than length (L > y)")
+        idx, _ = topl(sg.reshape(1, -1), L)              # the L best of the group, on the device
+        out.append((yg[idx[0]].sum(), yg.sum()))
+    return out
+
+
+def recallatL(y, yhat, grouping, L: int = 20) -> float:
+    """Mean recall@L per group (src/performance.jl:308-352); groups without positives give NaN (as the reference)."""
+    vals = [h / t if t > 0 else np.nan for h, t in _per_group_hits(y, yhat, grouping, L)]
+    return float(np.mean(vals))
+
+
+def precisionatL(y, yhat, grouping, L: int = 20) -> float:
+    """Mean precision@L per group (src/performance.jl:354-400)."""
+    return float(np.mean([h / L for h, _ in _per_group_hits(y, yhat, grouping, L)]))

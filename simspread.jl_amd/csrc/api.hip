@@ -1029,6 +1029,29 @@ int ss_predict_kfold_f64(ss_graph* g, const int32_t* fold_of_source, int nfolds,
   return predict_kfold_impl<double>(g, fold_of_source, nfolds, clean, out, ld, layout, mem);
 }
 
+int ss_topl_f32(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L, int32_t* idx, float* val,
+                int mem) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (nrows < 0 || ncols < 0 || ld < ncols) return fail(SS_EINVAL, "top-L: bad shape / leading dimension");
+  if (nrows == 0) return SS_OK;
+  if (!scores || !idx || !val) return fail(SS_EINVAL, "top-L: NULL buffer");
+  hipStream_t st = ctx().stream;
+  if (mem == SS_MEM_DEVICE) return launch_topl(scores, nrows, ncols, ld, L, idx, val);
+  DevBuf<float> ds, dv;
+  DevBuf<int> di;
+  SS_TRY(ds.alloc((size_t)nrows * ncols));
+  SS_TRY(dv.alloc((size_t)nrows * L));
+  SS_TRY(di.alloc((size_t)nrows * L));
+  SS_HIP(hipMemcpy2DAsync(ds.p, ncols * sizeof(float), scores, ld * sizeof(float), ncols * sizeof(float), nrows,
+                          hipMemcpyHostToDevice, st));
+  SS_TRY(launch_topl(ds.p, nrows, ncols, ncols, L, di.p, dv.p));
+  SS_HIP(hipMemcpyAsync(idx, di.p, (size_t)nrows * L * sizeof(int), hipMemcpyDeviceToHost, st));
+  SS_HIP(hipMemcpyAsync(val, dv.p, (size_t)nrows * L * sizeof(float), hipMemcpyDeviceToHost, st));
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
 int ss_spmat_create_csr_f32(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const float* val,
                             int index_base, int mem, ss_spmat** out) {
   return spmat_create_impl<float>(rows, cols, ptr, idx, val, index_base, mem, out);

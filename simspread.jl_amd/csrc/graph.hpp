@@ -187,6 +187,8 @@ int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, fl
 template <class T>
 int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
 
+int launch_topl(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L, int* oidx, float* oval);
+
 // ---- dense.hip (fp32 only: fp32-input MFMA)
 int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
                           int64_t row_begin, int64_t nrows, float* out, int64_t ldo);

@@ -1140,6 +1140,120 @@ int launch_fold_inverse(const int* kf, const int* ks, const int* fold, int phi, 
   return SS_OK;
 }
 
+// ============================================================== top-L per row (ranked evaluation on the device)
+// One workgroup per row.  Radix select (4 passes of 8 bits over an order-preserving integer image of the
+// float) finds the L-th largest key; elements above it are collected, ties at the threshold are taken in
+// ascending column order (what a stable descending sortperm does), then the L pairs are bitonic-sorted in LDS.
+__device__ __forceinline__ unsigned float_key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // larger float <=> larger key
+}
+
+constexpr int TOPL_THREADS = 256;
+constexpr int TOPL_MAX = 1024;
+
+__global__ void __launch_bounds__(TOPL_THREADS) topl_kernel(const float* __restrict__ scores, int64_t ncols, int64_t ld,
+                                                            int L, int* __restrict__ oidx, float* __restrict__ oval) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long sel[TOPL_MAX];  // (key << 32) | ~column : descending sort = score desc, column asc
+  __shared__ unsigned s_prefix, s_need, s_count, s_base;
+  const int tid = threadIdx.x;
+  const float* row = scores + (int64_t)blockIdx.x * ld;
+  if (tid == 0) { s_prefix = 0; s_need = (unsigned)L; }
+  __syncthreads();
+  // ---- radix select: after the loop s_prefix is the key of the L-th largest element,
+  //      s_need how many elements equal to it are wanted
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int64_t c = tid; c < ncols; c += TOPL_THREADS) {
+      const unsigned k = float_key(row[c]);
+      if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned need = s_need, b = 255;
+      for (;; --b) {  // buckets from the largest digit down
+        if (hist[b] >= need) break;
+        need -= hist[b];
+        if (b == 0) break;
+      }
+      s_prefix = prefix | (b << shift);
+      s_need = need;
+    }
+    __syncthreads();
+  }
+  const unsigned kth = s_prefix;
+  const unsigned need_eq = s_need;
+  if (tid == 0) { s_count = 0; s_base = 0; }
+  __syncthreads();
+  // ---- strictly above the threshold: any order (sorted afterwards)
+  for (int64_t c = tid; c < ncols; c += TOPL_THREADS) {
+    const unsigned k = float_key(row[c]);
+    if (k > kth) {
+      const unsigned p = atomicAdd(&s_count, 1u);
+      sel[p] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)c);
+    }
+  }
+  __syncthreads();
+  const unsigned above = s_count;
+  // ---- ties at the threshold: the first need_eq in column order (block-wide ordered compaction)
+  for (int64_t c0 = 0; c0 < ncols && s_base < need_eq; c0 += TOPL_THREADS) {
+    const int64_t c = c0 + tid;
+    const bool eq = c < ncols && float_key(row[c]) == kth;
+    // ordered rank of this thread among the equal ones of the chunk: wave ballots + per-wave offsets in hist[]
+    const unsigned long long m = __ballot(eq);
+    const int lane = tid & 63, w = tid >> 6;
+    if (lane == 0) hist[w] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned before = s_base;
+    for (int i = 0; i < w; ++i) before += hist[i];
+    const unsigned r = before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (eq && r < need_eq) sel[above + r] = ((unsigned long long)kth << 32) | (unsigned)(~(unsigned)c);
+    __syncthreads();
+    if (tid == 0) s_base += hist[0] + hist[1] + hist[2] + hist[3];
+    __syncthreads();
+  }
+  // ---- sort the L pairs descending (bitonic on the next power of two, padding with 0 = smallest)
+  int P = 1;
+  while (P < L) P <<= 1;
+  for (int i = L + tid; i < P; i += TOPL_THREADS) sel[i] = 0ull;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += TOPL_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = sel[i], b = sel[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) { sel[i] = b; sel[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < L; i += TOPL_THREADS) {
+    const unsigned long long e = sel[i];
+    const unsigned c = ~(unsigned)(e & 0xFFFFFFFFull);
+    oidx[(int64_t)blockIdx.x * L + i] = (int)c;
+    oval[(int64_t)blockIdx.x * L + i] = row[c];
+  }
+}
+
+int launch_topl(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L, int* oidx, float* oval) {
+  if (nrows <= 0) return SS_OK;
+  if (L < 1 || L > TOPL_MAX || L > ncols) return fail(SS_EINVAL, "top-L needs 1 <= L <= min(%d, ncols)", TOPL_MAX);
+  for (int64_t r0 = 0; r0 < nrows; r0 += (1 << 30)) {
+    const int64_t nb = nrows - r0 < (1 << 30) ? nrows - r0 : (1 << 30);
+    hipLaunchKernelGGL(topl_kernel, dim3((unsigned)nb), dim3(TOPL_THREADS), 0, ctx().stream, scores + r0 * ld, ncols, ld,
+                       L, oidx + r0 * L, oval + r0 * L);
+    SS_LAUNCH_CHECK();
+  }
+  return SS_OK;
+}
+
 // ============================================================== LOO clean! fix-up
 // In fold i target t has degree kt[t] - [Y[i,t] != 0] (src/core.jl:479): the kt == 0 columns are
 // flagged by the SpMM epilogue, here the columns whose single edge belongs to the query itself.

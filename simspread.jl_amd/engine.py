@@ -12,6 +12,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib as L
+from . import _lib as L_
 
 
 def _suffix(dtype) -> str:
@@ -357,3 +358,25 @@ class DeviceSpMat:
             self.close()
         except Exception:
             pass
+
+
+def topl(scores, L: int):
+    """The L best columns of every row of a score block, in the order ``sortperm(yhat, rev=true)`` gives (score
+    descending, ties by ascending column).  `scores`: C-order float32 numpy array or contiguous torch CUDA tensor
+    (nrows, ncols).  Returns (idx int32 (nrows, L), val float32 (nrows, L)) of the same kind as the input."""
+    lib = L_.lib()
+    if _is_torch(scores):
+        import torch
+        if scores.dtype != torch.float32 or not scores.is_contiguous():
+            raise TypeError("scores must be a contiguous float32 tensor")
+        nrows, ncols = scores.shape
+        idx = torch.empty((nrows, L), dtype=torch.int32, device=scores.device)
+        val = torch.empty((nrows, L), dtype=torch.float32, device=scores.device)
+        L_.check(lib.ss_topl_f32(scores.data_ptr(), nrows, ncols, ncols, L, idx.data_ptr(), val.data_ptr(), L_.SS_MEM_DEVICE))
+        return idx, val
+    a = np.ascontiguousarray(scores, dtype=np.float32)
+    nrows, ncols = a.shape
+    idx = np.empty((nrows, L), np.int32)
+    val = np.empty((nrows, L), np.float32)
+    L_.check(lib.ss_topl_f32(a.ctypes.data, nrows, ncols, ncols, L, idx.ctypes.data, val.ctypes.data, L_.SS_MEM_HOST))
+    return idx, val

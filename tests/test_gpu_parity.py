@@ -487,3 +487,39 @@ def test_kfold_equals_the_reference_fold_loop(dtype, monkeypatch):
     monkeypatch.delenv("SS_SELL_SORT")
     g = ss.DeviceGraph.from_dense(None, Xn.array.astype(dtype), Yarr.astype(dtype), dtype=dtype)
     assert_close(g.predict_kfold(np.arange(n, dtype=np.int32), n, clean=True), g.predict_loo(clean=True), dtype)
+
+
+# ----------------------------------------------------------------------------- ranked evaluation on the device
+def test_topl_matches_stable_descending_sort_with_ties():
+    rng = np.random.default_rng(17)
+    x = np.round(rng.random((37, 5000)).astype(np.float32) * 50) / 50      # heavy ties
+    x[3, :] = 0.25                                                         # a whole row of ties
+    x[5, 100:140] = -99.0
+    for L in (1, 20, 64, 333, 1024):
+        idx, val = ss.topl(x, L)
+        want = np.argsort(-x, axis=1, kind="stable")[:, :L]
+        np.testing.assert_array_equal(idx, want)
+        np.testing.assert_array_equal(val, np.take_along_axis(x, want, 1))
+
+
+def test_recall_precision_at_L_reference_kat_and_device_scores(kats):
+    k = kats["at_L"]
+    for case in k["cases"]:
+        assert ss.recallatL(k["y"], k["yhat"], k["grouping"], case["L"]) == pytest.approx(case["recall"])
+        assert ss.precisionatL(k["y"], k["yhat"], k["grouping"], case["L"]) == pytest.approx(case["precision"])
+    # scores stay on the device: top-20 of each leave-one-out row, hits from the labels
+    import torch
+    ss.use_torch_stream()
+    rng = np.random.default_rng(2)
+    n, nt = 400, 300
+    S = rng.random((n, n)).astype(np.float32); S = (S + S.T) / 2; np.fill_diagonal(S, 1.0)
+    Y = (rng.random((n, nt)) < 0.05).astype(np.float32)
+    g = ss.DeviceGraph.from_dense(None, S, Y, alpha=np.float32(0.7), weighted=True, dtype=np.float32)
+    out = torch.empty((n, nt), dtype=torch.float32, device="cuda")
+    g.predict_loo(clean=True, out=out)
+    idx, _ = ss.topl(out, 20)
+    host = out.cpu().numpy()
+    np.testing.assert_array_equal(idx.cpu().numpy(), np.argsort(-host, axis=1, kind="stable")[:, :20])
+    hits = np.take_along_axis(Y, idx.cpu().numpy().astype(np.int64), 1).sum(1)
+    grouping = np.repeat(np.arange(n), nt)
+    assert ss.precisionatL(Y.ravel(), host.ravel(), grouping, 20) == pytest.approx(hits.mean() / 20)
