@@ -15,6 +15,8 @@
  *     aborts; ss_last_error() returns a thread-local message for the last failure;
  *   - one process drives one GPU (ss_init(device)); multi-GPU = one process per GPU,
  *     rows/folds sharded by the host layer, RCCL only for the final score gather;
+ *   - entry points are serialised by one process-wide lock: calling from several host
+ *     threads / Julia tasks is safe, the calls just do not overlap;
  *   - `mem` says where caller buffers live: SS_MEM_HOST (copied during the call) or
  *     SS_MEM_DEVICE (used in place, e.g. a torch tensor's data_ptr()); the caller
  *     keeps ownership of every buffer it passes; the library owns what is behind

@@ -2,6 +2,7 @@
 // reference methods each entry point stands behind).  Host-side orchestration only: argument
 // checks, staging of caller buffers, the stage-1 / stage-2 launch sequence, event timing.
 #include <cstdlib>
+#include <mutex>
 #include <new>
 #include <type_traits>
 
@@ -794,6 +795,14 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
 // ==================================================================== extern "C"
 using namespace ss;
 
+// The library keeps one context per process (device, stream, timing of the last call).  Entry points that
+// touch it are serialised, so calls from several host threads / Julia tasks are safe (they do not overlap).
+static std::recursive_mutex& api_mutex() {
+  static std::recursive_mutex m;
+  return m;
+}
+#define SS_API_LOCK() std::lock_guard<std::recursive_mutex> _ss_api_guard(api_mutex())
+
 extern "C" {
 
 int ss_version(void) { return SS_VERSION; }
@@ -807,6 +816,7 @@ int ss_device_count(void) {
 }
 
 int ss_init(int device) {
+  SS_API_LOCK();
   Ctx& c = ctx();
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -828,6 +838,7 @@ int ss_init(int device) {
 }
 
 int ss_shutdown(void) {
+  SS_API_LOCK();
   Ctx& c = ctx();
   if (!c.inited) return SS_OK;
   (void)hipStreamSynchronize(c.stream);
@@ -844,6 +855,7 @@ int ss_shutdown(void) {
 }
 
 int ss_set_stream(void* hip_stream) {
+  SS_API_LOCK();
   SS_TRY(require_init());
   Ctx& c = ctx();
   SS_HIP(hipStreamSynchronize(c.stream));
@@ -852,6 +864,7 @@ int ss_set_stream(void* hip_stream) {
 }
 
 int ss_reset_stream(void) {
+  SS_API_LOCK();
   SS_TRY(require_init());
   Ctx& c = ctx();
   SS_HIP(hipStreamSynchronize(c.stream));
@@ -860,12 +873,14 @@ int ss_reset_stream(void) {
 }
 
 int ss_synchronize(void) {
+  SS_API_LOCK();
   SS_TRY(require_init());
   SS_HIP(hipStreamSynchronize(ctx().stream));
   return SS_OK;
 }
 
 int ss_timing_last(double* ms, int n) {
+  SS_API_LOCK();
   SS_TRY(require_init());
   if (!ms || n <= 0) return fail(SS_EINVAL, "ss_timing_last: bad buffer");
   Timing& t = ctx().timing;
@@ -887,22 +902,28 @@ int ss_timing_last(double* ms, int n) {
 
 int ss_cutoff_f32(const float* X, int64_t rows, int64_t cols, int64_t ld, float alpha, int weighted, float* out,
                   int64_t ldo, int mem) {
+  SS_API_LOCK();
   return cutoff_impl<float>(X, rows, cols, ld, alpha, weighted, out, ldo, mem);
 }
 int ss_cutoff_f64(const double* X, int64_t rows, int64_t cols, int64_t ld, double alpha, int weighted, double* out,
                   int64_t ldo, int mem) {
+  SS_API_LOCK();
   return cutoff_impl<double>(X, rows, cols, ld, alpha, weighted, out, ldo, mem);
 }
 int ss_row_degree_f32(const float* G, int64_t rows, int64_t cols, int64_t ld, int64_t* deg, int mem) {
+  SS_API_LOCK();
   return row_degree_impl<float>(G, rows, cols, ld, deg, mem);
 }
 int ss_row_degree_f64(const double* G, int64_t rows, int64_t cols, int64_t ld, int64_t* deg, int mem) {
+  SS_API_LOCK();
   return row_degree_impl<double>(G, rows, cols, ld, deg, mem);
 }
 int ss_spread_f32(const float* G, int64_t rows, int64_t cols, int64_t ld, float* W, int64_t ldw, int mem) {
+  SS_API_LOCK();
   return spread_impl<float>(G, rows, cols, ld, W, ldw, mem);
 }
 int ss_spread_f64(const double* G, int64_t rows, int64_t cols, int64_t ld, double* W, int64_t ldw, int mem) {
+  SS_API_LOCK();
   return spread_impl<double>(G, rows, cols, ld, W, ldw, mem);
 }
 
@@ -910,6 +931,7 @@ int ss_graph_create_csr_f32(int64_t nq, int64_t ns, int64_t nf, int64_t nt, cons
                             const int32_t* xq_idx, const float* xq_val, const int64_t* xs_ptr, const int32_t* xs_idx,
                             const float* xs_val, const int64_t* ys_ptr, const int32_t* ys_idx, const float* ys_val,
                             int index_base, int mem, ss_graph** out) {
+  SS_API_LOCK();
   return graph_create_csr_impl<float>(nq, ns, nf, nt, xq_ptr, xq_idx, xq_val, xs_ptr, xs_idx, xs_val, ys_ptr, ys_idx,
                                       ys_val, index_base, mem, out);
 }
@@ -917,18 +939,21 @@ int ss_graph_create_csr_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt, cons
                             const int32_t* xq_idx, const double* xq_val, const int64_t* xs_ptr, const int32_t* xs_idx,
                             const double* xs_val, const int64_t* ys_ptr, const int32_t* ys_idx, const double* ys_val,
                             int index_base, int mem, ss_graph** out) {
+  SS_API_LOCK();
   return graph_create_csr_impl<double>(nq, ns, nf, nt, xq_ptr, xq_idx, xq_val, xs_ptr, xs_idx, xs_val, ys_ptr, ys_idx,
                                        ys_val, index_base, mem, out);
 }
 int ss_graph_create_dense_f32(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const float* Sq, int64_t ldq,
                               const float* Ss, int64_t lds, const float* Y, int64_t ldy, int apply_cutoff, float alpha,
                               int weighted, int mem, ss_graph** out) {
+  SS_API_LOCK();
   return graph_create_dense_impl<float>(nq, ns, nf, nt, Sq, ldq, Ss, lds, Y, ldy, apply_cutoff, alpha, weighted, mem,
                                         out);
 }
 int ss_graph_create_dense_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt, const double* Sq, int64_t ldq,
                               const double* Ss, int64_t lds, const double* Y, int64_t ldy, int apply_cutoff,
                               double alpha, int weighted, int mem, ss_graph** out) {
+  SS_API_LOCK();
   return graph_create_dense_impl<double>(nq, ns, nf, nt, Sq, ldq, Ss, lds, Y, ldy, apply_cutoff, alpha, weighted, mem,
                                          out);
 }
@@ -937,6 +962,7 @@ int ss_graph_create_general_f32(int64_t n, int64_t nr, int64_t nc, const int64_t
                                 const float* l_val, const int64_t* b_ptr, const int32_t* b_idx, const float* b_val,
                                 const int64_t* w_ptr, const int32_t* w_idx, const float* w_val, int index_base, int mem,
                                 ss_graph** out) {
+  SS_API_LOCK();
   return graph_create_general_impl<float>(n, nr, nc, l_ptr, l_idx, l_val, b_ptr, b_idx, b_val, w_ptr, w_idx, w_val,
                                           index_base, mem, out);
 }
@@ -944,6 +970,7 @@ int ss_graph_create_general_f64(int64_t n, int64_t nr, int64_t nc, const int64_t
                                 const double* l_val, const int64_t* b_ptr, const int32_t* b_idx, const double* b_val,
                                 const int64_t* w_ptr, const int32_t* w_idx, const double* w_val, int index_base,
                                 int mem, ss_graph** out) {
+  SS_API_LOCK();
   return graph_create_general_impl<double>(n, nr, nc, l_ptr, l_idx, l_val, b_ptr, b_idx, b_val, w_ptr, w_idx, w_val,
                                            index_base, mem, out);
 }
@@ -951,11 +978,13 @@ int ss_graph_create_general_f64(int64_t n, int64_t nr, int64_t nc, const int64_t
 int ss_graph_create_similarity_f32(int64_t nq, int64_t ns, int64_t nt, const float* Sq, int64_t ldq, const float* Ss,
                                    int64_t lds, const int64_t* y_ptr, const int32_t* y_idx, const float* y_val,
                                    int index_base, float alpha, int weighted, int mem, ss_graph** out) {
+  SS_API_LOCK();
   return graph_create_similarity_impl(nq, ns, nt, Sq, ldq, Ss, lds, y_ptr, y_idx, y_val, index_base, alpha, weighted,
                                       mem, out);
 }
 
 int ss_graph_destroy(ss_graph* h) {
+  SS_API_LOCK();
   if (!h) return SS_OK;
   if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   const int dtype = *reinterpret_cast<int*>(h);
@@ -966,6 +995,7 @@ int ss_graph_destroy(ss_graph* h) {
 }
 
 int ss_graph_info(const ss_graph* h, int64_t sizes[7]) {
+  SS_API_LOCK();
   if (!h || !sizes) return fail(SS_EINVAL, "NULL argument");
   const int dtype = *reinterpret_cast<const int*>(h);
   auto fill = [&](auto* b) {
@@ -979,6 +1009,7 @@ int ss_graph_info(const ss_graph* h, int64_t sizes[7]) {
 }
 
 int ss_graph_degrees(const ss_graph* h, int64_t* kf, int64_t* ks, int64_t* kt) {
+  SS_API_LOCK();
   SS_TRY(require_init());
   if (!h) return fail(SS_EINVAL, "graph handle is NULL");
   const int dtype = *reinterpret_cast<const int*>(h);
@@ -1003,34 +1034,41 @@ int ss_graph_degrees(const ss_graph* h, int64_t* kf, int64_t* ks, int64_t* kt) {
 
 int ss_predict_f32(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean, float* out, int64_t ld,
                    int layout, int mem) {
+  SS_API_LOCK();
   if (rows_kind != SS_ROWS_QUERY && rows_kind != SS_ROWS_SOURCE) return fail(SS_EINVAL, "bad rows_kind");
   return predict_impl<float>(g, rows_kind, row_begin, row_end, clean, out, ld, layout, mem);
 }
 int ss_predict_f64(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean, double* out, int64_t ld,
                    int layout, int mem) {
+  SS_API_LOCK();
   if (rows_kind != SS_ROWS_QUERY && rows_kind != SS_ROWS_SOURCE) return fail(SS_EINVAL, "bad rows_kind");
   return predict_impl<double>(g, rows_kind, row_begin, row_end, clean, out, ld, layout, mem);
 }
 int ss_predict_loo_f32(ss_graph* g, int64_t i_begin, int64_t i_end, int clean, float* out, int64_t ld, int layout,
                        int mem) {
+  SS_API_LOCK();
   return predict_impl<float>(g, 2, i_begin, i_end, clean, out, ld, layout, mem);
 }
 int ss_predict_loo_f64(ss_graph* g, int64_t i_begin, int64_t i_end, int clean, double* out, int64_t ld, int layout,
                        int mem) {
+  SS_API_LOCK();
   return predict_impl<double>(g, 2, i_begin, i_end, clean, out, ld, layout, mem);
 }
 
 int ss_predict_kfold_f32(ss_graph* g, const int32_t* fold_of_source, int nfolds, int clean, float* out, int64_t ld,
                          int layout, int mem) {
+  SS_API_LOCK();
   return predict_kfold_impl<float>(g, fold_of_source, nfolds, clean, out, ld, layout, mem);
 }
 int ss_predict_kfold_f64(ss_graph* g, const int32_t* fold_of_source, int nfolds, int clean, double* out, int64_t ld,
                          int layout, int mem) {
+  SS_API_LOCK();
   return predict_kfold_impl<double>(g, fold_of_source, nfolds, clean, out, ld, layout, mem);
 }
 
 int ss_topl_f32(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L, int32_t* idx, float* val,
                 int mem) {
+  SS_API_LOCK();
   SS_TRY(require_init());
   SS_TRY(check_mem(mem));
   if (nrows < 0 || ncols < 0 || ld < ncols) return fail(SS_EINVAL, "top-L: bad shape / leading dimension");
@@ -1054,13 +1092,16 @@ int ss_topl_f32(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, i
 
 int ss_spmat_create_csr_f32(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const float* val,
                             int index_base, int mem, ss_spmat** out) {
+  SS_API_LOCK();
   return spmat_create_impl<float>(rows, cols, ptr, idx, val, index_base, mem, out);
 }
 int ss_spmat_create_csr_f64(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const double* val,
                             int index_base, int mem, ss_spmat** out) {
+  SS_API_LOCK();
   return spmat_create_impl<double>(rows, cols, ptr, idx, val, index_base, mem, out);
 }
 int ss_spmat_destroy(ss_spmat* h) {
+  SS_API_LOCK();
   if (!h) return SS_OK;
   if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   const int dtype = *reinterpret_cast<int*>(h);
@@ -1071,13 +1112,16 @@ int ss_spmat_destroy(ss_spmat* h) {
 }
 int ss_spmm_f32(ss_spmat* w, const float* R, int64_t B, int64_t ldr, int r_layout, float* F, int64_t ldf, int f_layout,
                 int mem) {
+  SS_API_LOCK();
   return spmm_impl<float>(w, R, B, ldr, r_layout, F, ldf, f_layout, mem);
 }
 int ss_spmm_f64(ss_spmat* w, const double* R, int64_t B, int64_t ldr, int r_layout, double* F, int64_t ldf,
                 int f_layout, int mem) {
+  SS_API_LOCK();
   return spmm_impl<double>(w, R, B, ldr, r_layout, F, ldf, f_layout, mem);
 }
 int ss_spmat_cost(const ss_spmat* h, int64_t B, double* bytes, double* flops) {
+  SS_API_LOCK();
   if (!h) return fail(SS_EINVAL, "matrix handle is NULL");
   const int dtype = *reinterpret_cast<const int*>(h);
   int64_t rows, cols, nnz;
