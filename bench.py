@@ -46,6 +46,18 @@ def synth_c2(nq, ns, nf, nt, dx, dy, seed, rank, weighted=True):
     return Xq, Xs, Ys
 
 
+def pmc_field(kernel_substr, field):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            d = json.load(f)
+        for k, v in d["kernels"].items():
+            if kernel_substr in k:
+                return v.get(field)
+    except Exception:
+        pass
+    return None
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md
@@ -282,7 +294,12 @@ def main():
         stage1 = {
             "kernel": "transfer_kernel<float,false,8> (stage 1, T = (Xq Df^-1) Xs' Ds^-1)",
             "avg_launch_ms": round(transfer_ms, 4),
-            "bound": "lds-scatter (see DESIGN.md 4.1); hbm and fp32-FMA fractions for reference",
+            "bound": "L2 bandwidth for short runs (DESIGN.md 4.1): every query re-reads 5 % of X' as ~62-entry sub-rows; "
+                     "tools/subrow_fetch_bench.hip measures 18.7 TB/s as the chip's ceiling for that pattern",
+            "l2_bytes": pmc_field("transfer_kernel", "l2_request_bytes_per_launch"),
+            "l2_peak_GBps_measured": 18700.0,
+            "frac_l2": (round(pmc_field("transfer_kernel", "l2_request_bytes_per_launch") / (transfer_ms * 1e-3) / 1e9 / 18700.0, 4)
+                        if pmc_field("transfer_kernel", "l2_request_bytes_per_launch") else None),
             "algorithmic_bytes": s1_bytes, "frac_hbm": round(s1_bytes / (transfer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "flops": s1_flops, "frac_fma": round(s1_flops / (transfer_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
             "traffic": pmc_traffic("transfer_kernel"),
