@@ -12,6 +12,10 @@ def avg(counter_dir, counter):
                     agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 fetch, write = avg("pmc_FETCH_SIZE", "FETCH_SIZE"), avg("pmc_WRITE_SIZE", "WRITE_SIZE")
+l2req = avg("pmc_TCC_HIT_sum", "TCC_REQ_sum")
+l2hit = avg("pmc_TCC_HIT_sum", "TCC_HIT_sum")
+ldsact = avg("pmc_SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")
+grbm = avg("pmc_SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")
 dur = defaultdict(list)
 for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
     with open(f) as fh:
@@ -25,6 +29,9 @@ for k in fetch:
         continue
     out["kernels"][k] = {"FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write.get(k),
                          "hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0)) * 1024,
+                         "l2_request_bytes_per_launch": l2req.get(k, 0) * 64,
+                         "l2_hit_rate": (l2hit.get(k, 0) / l2req[k]) if l2req.get(k) else None,
+                         "lds_busy_frac": ((ldsact.get(k, 0) / 256) / (grbm[k] / 8)) if grbm.get(k) else None,
                          "avg_duration_us": (sum(dur[k]) / len(dur[k]) / 1e3) if k in dur else None}
 for name in (f"pmc_{tag}.json", "pmc_latest.json"):
     with open(os.path.join(root, "profiles", name), "w") as f:
