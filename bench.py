@@ -194,6 +194,7 @@ def main():
                     help="c2: BASELINE configs[1] (default, the metric's config); c3loo: configs[2], 100k x 100k 1%% "
                          "leave-one-out, each rank scores --folds consecutive folds of its shard per step")
     ap.add_argument("--folds", type=int, default=2048, help="c3loo: folds per rank and step")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="compute type (the metric's config is f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the score blocks (outside `value`)")
@@ -228,8 +229,9 @@ def main():
 
     nq, n = args.nq, args.n
     Xq, Xs, Ys = synth_c2(nq, n, n, n, args.dx, args.dy, seed=20250222 + 2, rank=rank, weighted=not args.unweighted)
-    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
-    scores = torch.empty((nq, n), dtype=torch.float32, device="cuda")
+    np_dt, th_dt, vb = (np.float32, torch.float32, 4) if args.dtype == "f32" else (np.float64, torch.float64, 8)
+    g = ss.DeviceGraph.from_sparse(Xq.astype(np_dt), Xs.astype(np_dt), Ys.astype(np_dt), dtype=np_dt)
+    scores = torch.empty((nq, n), dtype=th_dt, device="cuda")
 
     def barrier():
         if world > 1:
@@ -271,11 +273,11 @@ def main():
         transfer_ms = float(np.mean(stage["transfer_ms"]))
         # dominant kernel: the W*R SpMM (stage 2).  Algorithmic work per launch:
         #   bytes = CSR(W) + K*B*4 + M*B*4,  flops = 2*nnz(W)*B,  B = nq columns of R per launch
-        spmm_bytes = csr_bytes(nnz_w, n) + n * nq * 4 + n * nq * 4
+        spmm_bytes = csr_bytes(nnz_w, n, vb) + n * nq * vb + n * nq * vb
         spmm_flops = 2.0 * nnz_w * nq
         achieved_tf = spmm_flops / (spmm_ms * 1e-3) / 1e12
         roofline = {
-            "kernel": "spmm_sell_kernel<float,4> (stage 2, F = W*R, B = %d)" % nq,
+            "kernel": "spmm_sell_kernel<%s> (stage 2, F = W*R, B = %d)" % ("float,4" if args.dtype == "f32" else "double,2", nq),
             "bound": "mfma",
             "bound_note": "wide-R SpMM is FMA/LDS-gather bound; peak = fp32 vector rate = fp32-input MFMA rate (157.3 TF)",
             "achieved": round(achieved_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -308,7 +310,7 @@ def main():
             "metric": "predicted edges/sec + achieved HBM GB/s, W*R SpMM",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d queries x %d targets per GPU, %d sources/features, "
                                    "%.0f%% similarity (%s), %.0f%% bipartite density, fp32, full predict()"
                                    % (nq, n, n, args.dx * 100, "unweighted" if args.unweighted else "weighted U(0.5,1]",
