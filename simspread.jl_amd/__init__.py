@@ -7,9 +7,10 @@ kernels in ``libsimspread_hip.so`` (C ABI: include/simspread_hip.h).  No CPU fal
 from . import _lib
 from ._lib import SimSpreadError, init, timing_last, use_torch_stream
 from .core import (NamedMatrix, Network, clean, clean_, construct, cutoff, featurize, k, names, precisionatL, predict,
-                   recallatL, save, split, spread)
+                   read_namedmatrix, recallatL, save, split, spread, writedlm)
 from .dist import gather_scores, shard_range
 from .engine import DeviceGraph, DeviceSpMat, topl
 
 __all__ = ["NamedMatrix", "Network", "DeviceGraph", "DeviceSpMat", "SimSpreadError", "init", "timing_last", "use_torch_stream",
-           "shard_range", "gather_scores", "k", "cutoff", "featurize", "construct", "spread", "predict", "clean", "clean_", "names", "split", "save", "topl", "recallatL", "precisionatL"]
+           "shard_range", "gather_scores", "k", "cutoff", "featurize", "construct", "spread", "predict", "clean", "clean_", "names", "split", "save", "topl", "recallatL", "precisionatL",
+           "read_namedmatrix", "writedlm"]

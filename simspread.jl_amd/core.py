@@ -396,6 +396,47 @@ def save(filepath: str, *args, delimiter: str = "\t") -> None:
                 f.write(delimiter.join(row) + "\n")
 
 
+# --------------------------------------------------------------------------- text I/O
+def _parse_matrix(M: List[List[str]], rows: bool = False, cols: bool = False, type=float) -> NamedMatrix:
+    """Cells of a delimited file -> NamedMatrix (src/utils.jl:26-40): names from the first column / row when
+    present, otherwise "R#i" / "C#j" (1-based); rows and columns are then reordered by *string* sort of the names
+    (so "R#10" sorts before "R#2", as in the reference)."""
+    r0, c0 = (1 if cols else 0), (1 if rows else 0)
+    body = [line[c0:] for line in M[r0:]]
+    width = len(body[0]) if body else 0
+    if any(len(line) != width for line in body):
+        raise ValueError("read_namedmatrix: ragged rows")
+    values = np.array([[type(v) for v in line] for line in body]).reshape(len(body), width)
+    row_names = [str(line[0]) for line in M[r0:]] if rows else [f"R#{i}" for i in range(1, len(body) + 1)]
+    col_names = [str(c) for c in M[0][c0:]] if cols else [f"C#{j}" for j in range(1, width + 1)]
+    named = NamedMatrix(values, row_names, col_names)
+    return named.sub(sorted(row_names), sorted(col_names))
+
+
+def read_namedmatrix(filepath: str, delimiter: str = " ", valuetype=float, rows: bool = True,
+                     cols: bool = True) -> NamedMatrix:
+    """read_namedmatrix(filepath, delimiter=' ', valuetype=Float64; rows=true, cols=true)  (src/utils.jl:52-55).
+    Every cell is read as a string (readdlm(..., String)) and split on the single delimiter character, so a
+    header line that starts with the delimiter has an empty corner cell (test/data/mat1)."""
+    with open(filepath) as f:
+        M = [line.rstrip("\n").rstrip("\r").split(delimiter) for line in f if line.strip("\r\n") != ""]
+    return _parse_matrix(M, rows, cols, type=valuetype)
+
+
+def writedlm(io, x: NamedMatrix, delimiter: str = "\t") -> None:
+    """writedlm(io, x::NamedMatrix[, delimiter])  (src/utils.jl:6-11): an empty corner cell and the column names,
+    then one line per row: name, values."""
+    own = isinstance(io, str)
+    f = open(io, "w") if own else io
+    try:
+        f.write(delimiter.join([""] + list(x.cols)) + "\n")
+        for name, line in zip(x.rows, x.array):
+            f.write(delimiter.join([str(name)] + [_julia_number(v) for v in line]) + "\n")
+    finally:
+        if own:
+            f.close()
+
+
 # --------------------------------------------------------------------------- ranked metrics (SURVEY 8f rank 3)
 def _per_group_hits(y, yhat, grouping, L: int):
     from .engine import topl
