@@ -100,11 +100,14 @@ def spmm_sweep(ss, torch, steps=5):
     nnz = int(keys.numel())
     del keys, r
     val = torch.rand(nnz, device=dev, dtype=torch.float32, generator=g) + 0.5
+    if os.environ.get("SWEEP_BINARY") == "1":   # pattern-only operand (SimSpread's own W = Ys' is binary)
+        val.fill_(1.0)
     lib = L.lib()
     h = C.c_void_p()
     L.check(lib.ss_spmat_create_csr_f32(M, K, ptr.data_ptr(), idx.data_ptr(), val.data_ptr(), 0, L.SS_MEM_DEVICE, C.byref(h)))
     out = []
-    for B in (1, 4, 16, 64):
+    widths = tuple(int(x) for x in os.environ.get("SWEEP_B", "1,4,16,64").split(","))
+    for B in widths:
         R = torch.rand(K, B, device=dev, dtype=torch.float32, generator=g)
         F = torch.empty(M, B, device=dev, dtype=torch.float32)
         ms = []

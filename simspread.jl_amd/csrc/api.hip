@@ -691,11 +691,36 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   // kernel (SS_NARROW_REGACC=1) and 5.6 ms for gathering rows of R from L2 (SS_NARROW_CSR=1))
   int wide_from = 9;
   if (const char* e = getenv("SS_WIDE_FROM")) wide_from = atoi(e);
+  // 8 < B <= 64, row-major: row-block ELL kernel (spmm_mid.hip), one pass over W per 16 columns (fp64: 8), no
+  // partial sums; SS_MID=0 or a matrix whose rows do not fit the ELL slots: wide kernel as before
+  int mid_from = 9;
+  if (const char* e = getenv("SS_MID_FROM")) mid_from = atoi(e);
+  const bool mid = (B >= mid_from && B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR &&
+                    !(getenv("SS_MID") && atoi(getenv("SS_MID")) == 0) && getenv("SS_WIDE_FROM") == nullptr &&
+                    getenv("SS_NARROW_REGACC") == nullptr && getenv("SS_NARROW_CSR") == nullptr);
   const bool wide_for_mid = (B >= wide_from && getenv("SS_NARROW_REGACC") == nullptr && getenv("SS_NARROW_CSR") == nullptr);
   const bool narrow = (B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR && !wide_for_mid);
   DevBuf<T> Rt, Ft;
   const bool use_csr_gather = getenv("SS_NARROW_CSR") != nullptr;
-  if (narrow && B <= 16 && !use_csr_gather) {
+  bool use_ell = false;
+  if (mid) {
+    if (m.ell_state == 0) {
+      SS_TRY(ell_build<T>(m.csr, m.ell));
+      // long or skewed rows would live mostly in the overflow list: those matrices keep the wide kernel
+      m.ell_state = ((double)m.ell.overflow <= 0.15 * (double)m.ell.nnz) ? 1 : -1;
+      if (m.ell_state < 0) m.ell = DevEll<T>();
+    }
+    use_ell = m.ell_state == 1;
+  }
+  if (use_ell) {
+    StageTimer t2(ST_SPMM);
+    const int bv = mid_tile_cols<T>();
+    for (int64_t j0 = 0; j0 < B; j0 += bv) {
+      const int bn = (int)((B - j0 < bv) ? (B - j0) : bv);
+      SS_TRY(launch_spmm_ell<T>(m.ell, Rd + j0, ldr_d, bn, Fd + j0, ldf_d));
+      timing_count(ST_NSPMM, 1);
+    }
+  } else if (narrow && B <= 16 && !use_csr_gather) {
     // R chunk resident in LDS, W streamed once in chunk-major order (HBM-bound regime)
     int slot = 0, bv = 1;
     while (bv < B) { bv <<= 1; ++slot; }

@@ -379,6 +379,25 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
         assert_close(ws.spmm(R.astype(dt)), W @ R, dt)
 
 
+@pytest.mark.parametrize("dtype,B", [(np.float32, 16), (np.float32, 24), (np.float32, 50), (np.float64, 12), (np.float64, 32)])
+def test_spmm_mid_width_row_blocks(dtype, B, monkeypatch):
+    """8 < B <= 64: row-block kernel (spmm_mid.hip) with several rows per lane group and several LDS chunks of R;
+    SS_MID=0 (the wide kernel) must give the same numbers to rounding."""
+    rng = np.random.default_rng(B)
+    M, K = 30011, 2900
+    W = sp.random(M, K, density=0.012, format="csr", random_state=rng, dtype=np.float64)
+    W.data = rng.random(W.nnz) + 0.5
+    R = rng.standard_normal((K, B))
+    want = W @ R
+    monkeypatch.setenv("SS_NARROW_CHUNK", "600")     # 5 chunks of R
+    w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
+    got = w.spmm(R.astype(dtype))
+    assert_close_signed(got, want, dtype)
+    assert np.array_equal(got, w.spmm(R.astype(dtype)))          # fixed summation order: bitwise repeatable
+    monkeypatch.setenv("SS_MID", "0")
+    assert_close_signed(ss.DeviceSpMat(W.astype(dtype), dtype=dtype).spmm(R.astype(dtype)), want, dtype)
+
+
 def test_power_law_graph_predict_with_sorted_split_operand(monkeypatch):
     rng = np.random.default_rng(12)
     ns, nt, nq = 600, 500, 77
