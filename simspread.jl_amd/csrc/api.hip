@@ -685,41 +685,37 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   }
   hipEvent_t e_begin, e_end;
   SS_TRY(timing_mark(&e_begin));
-  // row-major operands: B <= 8 streams W once with R chunks in LDS (HBM-bound kernel); 8 < B <= 64 goes, by
+  // row-major operands: B <= 8 streams W once with R chunks in LDS (HBM-bound kernel); 32 < B <= 64 goes, by
   // default, to the wide LDS-tiled kernel with the slices split over workgroups (W is then streamed B/4 times:
-  // measured at 100k x 100k / 1 %: B=16 0.55 ms vs 0.71 ms, B=64 1.18 ms vs 4.9 ms for the register-accumulator
-  // kernel (SS_NARROW_REGACC=1) and 5.6 ms for gathering rows of R from L2 (SS_NARROW_CSR=1))
+  // measured at 100k x 100k / 1 %: B=64 1.18 ms vs 4.9 ms for the register-accumulator kernel
+  // (SS_NARROW_REGACC=1) and 5.6 ms for gathering rows of R from L2 (SS_NARROW_CSR=1))
   int wide_from = 9;
   if (const char* e = getenv("SS_WIDE_FROM")) wide_from = atoi(e);
-  // 8 < B <= 64, row-major: row-block ELL kernel (spmm_mid.hip), one pass over W per 16 columns (fp64: 8), no
-  // partial sums; SS_MID=0 or a matrix whose rows do not fit the ELL slots: wide kernel as before
-  int mid_from = 9;
-  if (const char* e = getenv("SS_MID_FROM")) mid_from = atoi(e);
-  const bool mid = (B >= mid_from && B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR &&
-                    !(getenv("SS_MID") && atoi(getenv("SS_MID")) == 0) && getenv("SS_WIDE_FROM") == nullptr &&
-                    getenv("SS_NARROW_REGACC") == nullptr && getenv("SS_NARROW_CSR") == nullptr);
+  // 8 < B <= 32 (fp64: 16), row-major: row-block kernel (spmm_mid.hip): W streamed once, no partial sums.
+  // Measured at 100k x 100k / 1 %: B=16 0.37 ms (wide kernel 0.56), B=32 0.74 (1.03); SS_MID=0: wide kernel
+  const bool mid = (B > 8 && B * (int64_t)sizeof(T) <= 128 && r_layout == SS_LAYOUT_ROWMAJOR &&
+                    f_layout == SS_LAYOUT_ROWMAJOR && !(getenv("SS_MID") && atoi(getenv("SS_MID")) == 0) &&
+                    getenv("SS_WIDE_FROM") == nullptr && getenv("SS_NARROW_REGACC") == nullptr &&
+                    getenv("SS_NARROW_CSR") == nullptr);
   const bool wide_for_mid = (B >= wide_from && getenv("SS_NARROW_REGACC") == nullptr && getenv("SS_NARROW_CSR") == nullptr);
   const bool narrow = (B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR && !wide_for_mid);
   DevBuf<T> Rt, Ft;
   const bool use_csr_gather = getenv("SS_NARROW_CSR") != nullptr;
-  bool use_ell = false;
   if (mid) {
-    if (m.ell_state == 0) {
-      SS_TRY(ell_build<T>(m.csr, m.ell));
-      // long or skewed rows would live mostly in the overflow list: those matrices keep the wide kernel
-      m.ell_state = ((double)m.ell.overflow <= 0.15 * (double)m.ell.nnz) ? 1 : -1;
-      if (m.ell_state < 0) m.ell = DevEll<T>();
+    const int slot = (B <= 16 && sizeof(T) == 4) ? 0 : 1;  // 64-byte tile rows (16 floats) or 128-byte (32 floats, 16 doubles)
+    const int bv = (slot == 0 ? 64 : 128) / (int)sizeof(T);
+    DevChunked<T>& op = m.mid[slot];
+    if (op.SC == 0) {
+      int kc = mid_chunk_cols<T>(bv);
+      if (const char* e = getenv("SS_NARROW_CHUNK")) {
+        const int v = atoi(e);
+        if (v >= 16 && v < kc) kc = v;
+      }
+      SS_TRY(chunked_build<T>(m.csr, kc, 4, op));
     }
-    use_ell = m.ell_state == 1;
-  }
-  if (use_ell) {
     StageTimer t2(ST_SPMM);
-    const int bv = mid_tile_cols<T>();
-    for (int64_t j0 = 0; j0 < B; j0 += bv) {
-      const int bn = (int)((B - j0 < bv) ? (B - j0) : bv);
-      SS_TRY(launch_spmm_ell<T>(m.ell, Rd + j0, ldr_d, bn, Fd + j0, ldf_d));
-      timing_count(ST_NSPMM, 1);
-    }
+    SS_TRY(launch_spmm_rowblock<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d));
+    timing_count(ST_NSPMM, 1);
   } else if (narrow && B <= 16 && !use_csr_gather) {
     // R chunk resident in LDS, W streamed once in chunk-major order (HBM-bound regime)
     int slot = 0, bv = 1;

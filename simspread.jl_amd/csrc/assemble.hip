@@ -795,129 +795,6 @@ int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out) {
   return SS_OK;
 }
 
-// ------------------------------------------------------------------ CSR -> row-block ELL (mid-width SpMM operand)
-// thread per (row, chunk), row-major so that the scan gives each row's overflow entries one contiguous range
-__global__ void ell_excess_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, int64_t rows, int KC,
-                                  int nchunks, int cap, int* __restrict__ ex) {
-  const int64_t total = rows * nchunks;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / nchunks;
-    const int c = (int)(i - r * nchunks);
-    const int lo = ptr[r], hi = ptr[r + 1];
-    const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
-    int a = lo, b = hi;
-    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
-    const int first = a;
-    b = hi;
-    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
-    const int n = a - first;
-    ex[i] = n > cap ? n - cap : 0;
-  }
-}
-
-__global__ void ell_optr_kernel(const int* __restrict__ eoff, int64_t rows, int nchunks, int* __restrict__ optr) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= rows; r += (int64_t)gridDim.x * blockDim.x)
-    optr[r] = eoff[r * nchunks];
-}
-
-// wave per (chunk, row): the first `cap` entries into the fixed slot, the rest to the overflow list
-template <class T>
-__global__ void ell_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
-                                int64_t rows, int KC, int nchunks, int cap, const int* __restrict__ eoff,
-                                unsigned short* __restrict__ eidx, T* __restrict__ eval, int* __restrict__ oidx,
-                                T* __restrict__ oval) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t total = rows * nchunks;
-  for (int64_t i = wave0; i < total; i += nwaves) {
-    const int c = (int)(i / rows);
-    const int64_t r = i - (int64_t)c * rows;
-    const int lo = ptr[r], hi = ptr[r + 1];
-    const int64_t k0 = (int64_t)c * KC, k1 = k0 + KC;
-    int a = lo, b = hi;
-    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
-    const int first = a;
-    b = hi;
-    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
-    const int n = a - first;
-    const int64_t slot = i * cap;
-    const int64_t obase = eoff[r * nchunks + c];
-    for (int x = lane; x < n; x += 64) {
-      const int k = idx[first + x];
-      if (x < cap) {
-        eidx[slot + x] = (unsigned short)(k - k0);
-        if (eval) eval[slot + x] = val[first + x];
-      } else {
-        oidx[obase + (x - cap)] = k;
-        oval[obase + (x - cap)] = val[first + x];
-      }
-    }
-  }
-}
-
-template <class T>
-int ell_build(const DevCsr<T>& in, DevEll<T>& out) {
-  hipStream_t st = ctx().stream;
-  out.rows = in.rows; out.cols = in.cols; out.nnz = in.nnz; out.binary = in.binary;
-  out.KC = mid_chunk_rows<T>();
-  if (const char* e = getenv("SS_MID_CHUNK")) {
-    const int v = atoi(e);
-    if (v >= 16 && v < out.KC) out.KC = v;
-  }
-  out.nchunks = (int)(in.cols > 0 ? ceil_div(in.cols, out.KC) : 1);
-  // slot width: the power of two (in quads) that covers the mean sub-row length plus ~1.2 sigma
-  const double lam = in.rows > 0 ? (double)in.nnz / ((double)in.rows * out.nchunks) : 0.0;
-  const double want = lam + 1.2 * sqrt(lam);
-  int gl = 2;
-  while (gl < 16 && 4 * gl < want) gl <<= 1;
-  if (const char* e = getenv("SS_MID_GL")) {
-    const int v = atoi(e);
-    if (v == 2 || v == 4 || v == 8 || v == 16) gl = v;
-  }
-  out.GL = gl;
-  const int cap = 4 * gl;
-  const int64_t total = in.rows * out.nchunks;
-  if (total * cap >= (1LL << 40)) return fail(SS_EUNSUPPORTED, "ELL operand too large");
-  SS_TRY(out.idx.alloc((size_t)total * cap + 64));
-  SS_HIP(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(out.idx.p), (unsigned short)out.KC, (size_t)total * cap + 64, st));
-  if (!in.binary) {
-    SS_TRY(out.val.alloc((size_t)total * cap + 64));
-    SS_HIP(hipMemsetAsync(out.val.p, 0, ((size_t)total * cap + 64) * sizeof(T), st));
-  } else {
-    SS_TRY(out.val.alloc(1));
-  }
-  SS_TRY(out.optr.alloc(in.rows + 1));
-  out.overflow = 0;
-  if (total == 0) {
-    SS_HIP(hipMemsetAsync(out.optr.p, 0, (in.rows + 1) * sizeof(int), st));
-    SS_TRY(out.oidx.alloc(1));
-    SS_TRY(out.oval.alloc(1));
-    return SS_OK;
-  }
-  DevBuf<int> ex, eoff;
-  SS_TRY(ex.alloc(total));
-  SS_TRY(eoff.alloc(total + 1));
-  hipLaunchKernelGGL(ell_excess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p, in.rows, out.KC,
-                     out.nchunks, cap, ex.p);
-  SS_LAUNCH_CHECK();
-  SS_TRY(exclusive_scan_int(ex.p, eoff.p, total));
-  int nover = 0;
-  SS_TRY(read_int(eoff.p + total, &nover));
-  out.overflow = nover;
-  SS_TRY(out.oidx.alloc((size_t)nover + 1));
-  SS_TRY(out.oval.alloc((size_t)nover + 1));
-  hipLaunchKernelGGL(ell_optr_kernel, dim3(grid_for(in.rows + 1, 256)), dim3(256), 0, st, eoff.p, in.rows, out.nchunks,
-                     out.optr.p);
-  SS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ell_fill_kernel<T>, dim3(grid_for(total * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p, in.val.p,
-                     in.rows, out.KC, out.nchunks, cap, eoff.p, out.idx.p, in.binary ? (T*)nullptr : out.val.p, out.oidx.p,
-                     out.oval.p);
-  SS_LAUNCH_CHECK();
-  SS_HIP(hipStreamSynchronize(st));
-  return SS_OK;
-}
-
 // ------------------------------------------------------------------ CSR -> chunk-major (offset, value) pairs
 __global__ void pairs_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const float* __restrict__ val,
                                   int64_t rows, int KC, int nchunks, int row_bytes, const int* __restrict__ off,
@@ -1053,7 +930,6 @@ int graph_finalize_general_targets(Graph<float>& g) {
   template int csr_from_dense<T>(const T*, int64_t, int64_t, int64_t, bool, T, bool, int, DevCsr<T>&);         \
   template int csr_transpose<T>(const DevCsr<T>&, DevCsr<T>&);                                                 \
   template int chunked_build<T>(const DevCsr<T>&, int, int, DevChunked<T>&);                                     \
-  template int ell_build<T>(const DevCsr<T>&, DevEll<T>&);                                                      \
   template int sell_build<T>(const DevCsr<T>&, int, DevSell<T>&);                                              \
   template int graph_finalize<T>(Graph<T>&);                                                                   \
   template int graph_finalize_general<T>(Graph<T>&);

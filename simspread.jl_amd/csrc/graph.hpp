@@ -102,32 +102,15 @@ struct DevPairs {
   DevBuf<uint2> ent;      // [nnz + 8]
 };
 
-// Row-block ELL operand of the mid-width SpMM (spmm_mid.hip): column chunks of KC like DevChunked, but every
-// sub-row (chunk c, row m) owns a fixed slot of GL quads at ((c*rows + m)*GL + q) -- no offset array, so the
-// kernel's loads do not depend on one another -- padded with (KC, 0); the few entries beyond 4*GL of a
-// sub-row go to an overflow CSR with global column indices.
-template <class T>
-struct DevEll {
-  int64_t rows = 0, cols = 0, nnz = 0, overflow = 0;
-  int KC = 0, nchunks = 0, GL = 0;
-  bool binary = false;
-  DevBuf<unsigned short> idx;  // [nchunks][rows][GL][4]
-  DevBuf<T> val;               // same shape (empty when binary)
-  DevBuf<int> optr;            // [rows + 1]
-  DevBuf<int> oidx;            // [overflow] global column
-  DevBuf<T> oval;
-};
-
 template <class T>
 struct SpMat {
   DevCsr<T> csr;
   DevSell<T> sell;
   int sell_qt = 0;
-  DevChunked<T> narrow[7];  // quad-aligned chunked operands for B <= 1, 2, 4, 8, 16, 32, 64 (built lazily)
+  DevChunked<T> narrow[5];  // quad-aligned chunked operands for B <= 1, 2, 4, 8, 16 (built lazily)
+  DevChunked<T> mid[2];     // operands of the mid-width kernel: 64- and 128-byte tile rows (built lazily)
   DevPairs pairs;           // operand of the register-accumulator kernel (16 < B <= 64, fp32)
   DevBuf<T> partial;        // [nchunks][rows][BV] partial sums of the narrow kernel
-  DevEll<T> ell;            // operand of the mid-width kernel (8 < B <= 64)
-  int ell_state = 0;        // 0 not built, 1 usable, -1 not suited (too much overflow): wide kernel instead
 };
 
 // ---- assemble.hip
@@ -198,16 +181,12 @@ int narrow_chunk_cols(int bv);  // KC for a padded width bv
 template <class T>
 int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
                                DevBuf<T>& partial);
-// stage 2, mid width (8 < B <= 64; fp64: <= 32): a workgroup owns rows, accumulators stay in registers while the
-// chunks of R cycle through LDS (spmm_mid.hip); same chunked operand as the narrow kernel
+// stage 2, mid width (8 < B <= 32; fp64: <= 16): a workgroup owns rows, accumulators stay in registers while the
+// chunks of R cycle through LDS (spmm_mid.hip); same chunked operand format as the narrow kernel
 template <class T>
-int ell_build(const DevCsr<T>& in, DevEll<T>& out);  // assemble.hip; KC and GL chosen from the shape
+int mid_chunk_cols(int bv);
 template <class T>
-int mid_tile_cols();   // columns of R per pass (16 floats / 8 doubles: 64-byte rows)
-template <class T>
-int mid_chunk_rows();  // KC: two half-width tiles of KC+1 rows fill the 160 KB of LDS
-template <class T>
-int launch_spmm_ell(const DevEll<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
+int launch_spmm_rowblock(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
 // stage 2, 16 < B <= 64 (fp32): accumulators in registers (lane = column), R chunk in LDS, entries by s_load
 int pairs_build(const DevCsr<float>& in, int KC, int row_bytes, DevPairs& out);
 int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf);

@@ -381,8 +381,8 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
 
 @pytest.mark.parametrize("dtype,B", [(np.float32, 16), (np.float32, 24), (np.float32, 50), (np.float64, 12), (np.float64, 32)])
 def test_spmm_mid_width_row_blocks(dtype, B, monkeypatch):
-    """8 < B <= 64: row-block kernel (spmm_mid.hip) with several rows per lane group and several LDS chunks of R;
-    SS_MID=0 (the wide kernel) must give the same numbers to rounding."""
+    """8 < B <= 32 (fp64: 16): row-block kernel (spmm_mid.hip) with several rows per lane group and several LDS
+    chunks of R (wider cases take the wide kernel); SS_MID=0 (the wide kernel) must agree to rounding."""
     rng = np.random.default_rng(B)
     M, K = 30011, 2900
     W = sp.random(M, K, density=0.012, format="csr", random_state=rng, dtype=np.float64)
