@@ -684,11 +684,32 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
   const int64_t k0 = (int64_t)c * a.KC;
   const int kn = (int)((a.K - k0 < a.KC) ? (a.K - k0) : a.KC);
 
+  // 32-byte tile rows (two 16-byte halves per non-zero): all lanes fetch the same half at the same time, so with
+  // a plain layout only every other 16-byte slot of the 256-byte LDS line is ever hit (a fixed 2-way conflict);
+  // half h of row k is stored at h ^ ((k >> 3) & 1), which spreads random k over all 16 slots
+  constexpr bool SWZ = (LPN == 1) && (BV * sizeof(T) == 32);
+  constexpr int HB = 16 / (int)sizeof(T);  // values per 16-byte half
   for (int e = tid; e < (a.KC + 1) * BV; e += blockDim.x) {
     const int k = e / BV, b = e - k * BV;
-    tile[e] = (k < kn && b < a.B) ? a.R[(k0 + k) * a.ldr + b] : T(0);
+    const T v = (k < kn && b < a.B) ? a.R[(k0 + k) * a.ldr + b] : T(0);
+    if constexpr (SWZ) tile[k * BV + ((((b / HB) ^ (k >> 3)) & 1) * HB) + (b % HB)] = v;
+    else tile[e] = v;
   }
   __syncthreads();
+  auto tile_row = [&](int k) __attribute__((always_inline)) {
+    V r;
+    if constexpr (SWZ) {
+      using H = Vec<T, HB>;
+      const int s = (k >> 3) & 1;
+      const H lo = *reinterpret_cast<const H*>(&tile[k * BV + s * HB]);
+      const H hi = *reinterpret_cast<const H*>(&tile[k * BV + (s ^ 1) * HB]);
+#pragma unroll
+      for (int i = 0; i < HB; ++i) { r.v[i] = lo.v[i]; r.v[HB + i] = hi.v[i]; }
+    } else {
+      r = *reinterpret_cast<const V*>(&tile[k * BV]);
+    }
+    return r;
+  };
 
   const int* __restrict__ off = a.off + (int64_t)c * a.M;
   if (LPN == 1) {
@@ -721,10 +742,10 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[u][i] = T(0);
         if (has) {
-          const V r0 = *reinterpret_cast<const V*>(&tile[(int)iv[u].x * BV]);
-          const V r1 = *reinterpret_cast<const V*>(&tile[(int)iv[u].y * BV]);
-          const V r2 = *reinterpret_cast<const V*>(&tile[(int)iv[u].z * BV]);
-          const V r3 = *reinterpret_cast<const V*>(&tile[(int)iv[u].w * BV]);
+          const V r0 = tile_row((int)iv[u].x);
+          const V r1 = tile_row((int)iv[u].y);
+          const V r2 = tile_row((int)iv[u].z);
+          const V r3 = tile_row((int)iv[u].w);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             acc[u][i] = fma(w[u].v[0], r0.v[i], acc[u][i]);
@@ -736,10 +757,10 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
         for (int q = o[u] + gl + GL; q < oe[u]; q += GL) {  // sub-rows longer than one group step
           const ushort4 jv = ip[q];
           const Vec<T, 4> x = vp[q];
-          const V r0 = *reinterpret_cast<const V*>(&tile[(int)jv.x * BV]);
-          const V r1 = *reinterpret_cast<const V*>(&tile[(int)jv.y * BV]);
-          const V r2 = *reinterpret_cast<const V*>(&tile[(int)jv.z * BV]);
-          const V r3 = *reinterpret_cast<const V*>(&tile[(int)jv.w * BV]);
+          const V r0 = tile_row((int)jv.x);
+          const V r1 = tile_row((int)jv.y);
+          const V r2 = tile_row((int)jv.z);
+          const V r3 = tile_row((int)jv.w);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             acc[u][i] = fma(x.v[0], r0.v[i], acc[u][i]);
