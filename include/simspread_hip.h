@@ -199,6 +199,15 @@ int ss_predict_kfold_f64(ss_graph* g, const int32_t* fold_of_source, int nfolds,
 int ss_topl_f32(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L,
                 int32_t* idx, float* val, int mem);
 
+/* Threshold-free evaluation of one score vector on the device ("next" row of the scope table):
+ * out[0] = AuROC, out[1] = AuPRC (src/performance.jl:49-89: confusion matrix at every unique score, a sample is
+ * predicted positive when score >= threshold, trapezoidal rule over exactly those points), out[2] =
+ * BEDROC(alpha) (src/performance.jl:22-38; ranks in sortperm(yhat, rev=true) order), out[3] = validity ratio
+ * (share of non-zero scores, src/performance.jl:558-560).  y: n labels (0 = negative, anything else =
+ * positive), yhat: n scores; both host or both device (mem); out is always host memory.  n < 2^31.
+ * AuROC/AuPRC are NaN when a class is missing, as in the reference. */
+int ss_rank_metrics_f32(const uint8_t* y, const float* yhat, int64_t n, double alpha, double out[4], int mem);
+
 /* -------------------------------------------------------------- raw W*R SpMM --- */
 /* The resource-spreading product F = W * R on its own (kernel unit tests and the
  * roofline benchmark; inside predict W = Ys' and R = the transfer block, src/core.jl:413).

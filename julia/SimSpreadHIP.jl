@@ -187,4 +187,20 @@ function cutoff(X::Matrix{Float64}, alpha::Float64, weighted::Bool=false)
     return out
 end
 
+"""
+    rank_metrics(y, yhat; alpha=20.0) -> (AuROC, AuPRC, BEDROC, validity_ratio)
+
+The threshold-free metrics of `src/performance.jl:22-89,558-560` for one label / score vector, computed on the
+device (sort + prefix sums); `SimSpread.AuROC(y, yhat)` etc. become one-liners over this call.
+"""
+function rank_metrics(y::AbstractVector, yhat::AbstractVector; alpha::Float64=20.0)
+    length(y) == length(yhat) || throw(AssertionError("The number of scores must be equal to the number of labels"))
+    labels = Vector{UInt8}(y .!= 0)
+    scores = Vector{Float32}(yhat)
+    out = Vector{Float64}(undef, 4)
+    check(ccall((:ss_rank_metrics_f32, LIB), Cint, (Ptr{UInt8}, Ptr{Float32}, Int64, Float64, Ptr{Float64}, Cint),
+                labels, scores, length(scores), alpha, out, SS_MEM_HOST))
+    return (AuROC=out[1], AuPRC=out[2], BEDROC=out[3], validity_ratio=out[4])
+end
+
 end # module

@@ -349,3 +349,56 @@ def synth_bipartite(nq: int, ns: int, nf: int, nt: int, dx: float, dy: float, se
         Xs.sort_indices()
     Ys = rand_csr(ns, nt, dy, lambda n: np.ones(n))
     return Xq.astype(dtype), Xs.astype(dtype), Ys.astype(dtype)
+
+
+# --------------------------------------------------------------------------- threshold-free metrics
+# Literal restatement of src/performance.jl:22-89 with MLBase's roc(gt, scores, thresholds) (positive when
+# score >= threshold) and Trapz.trapz.  The reference's own tests for these are `skip = true`
+# (test/runtests.jl:210-223): parity unpinned.
+def _confusion_rates(y, yhat):
+    y = np.asarray(y).ravel() != 0
+    yhat = np.asarray(yhat, dtype=np.float64).ravel()
+    thresholds = np.unique(yhat)                      # sort(unique(yhat))
+    P, N = y.sum(), (~y).sum()
+    tp = np.array([(y & (yhat >= t)).sum() for t in thresholds], dtype=np.float64)
+    fp = np.array([(~y & (yhat >= t)).sum() for t in thresholds], dtype=np.float64)
+    return tp, fp, float(P), float(N)
+
+
+def _trapz(x, y):
+    return float(np.sum((x[1:] - x[:-1]) * (y[1:] + y[:-1]) / 2.0))
+
+
+def auroc(y, yhat):
+    """src/performance.jl:49-63"""
+    tp, fp, P, N = _confusion_rates(y, yhat)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return abs(_trapz(fp / N, tp / P))
+
+
+def auprc(y, yhat):
+    """src/performance.jl:74-89"""
+    tp, fp, P, N = _confusion_rates(y, yhat)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return abs(_trapz(tp / P, tp / (tp + fp)))
+
+
+def bedroc(y, yhat, rev=True, alpha=20.0):
+    """src/performance.jl:22-38; sortperm is stable, so ties keep their position order"""
+    y = np.asarray(y).ravel() != 0
+    yhat = np.asarray(yhat, dtype=np.float64).ravel()
+    N, n = len(y), int(y.sum())
+    order = np.argsort(-yhat if rev else yhat, kind="stable")
+    r = np.flatnonzero(y[order]) + 1
+    s = np.sum(np.exp(-alpha * r / N))
+    Ra = n / N
+    rand_sum = Ra * (1 - np.exp(-alpha)) / (np.exp(alpha / N) - 1)
+    fac = Ra * np.sinh(alpha / 2) / (np.cosh(alpha / 2) - np.cosh(alpha / 2 - alpha * Ra))
+    cte = 1 / (1 - np.exp(alpha * (1 - Ra)))
+    return float(s * fac / rand_sum + cte)
+
+
+def validity_ratio(yhat):
+    """src/performance.jl:558-560"""
+    yhat = np.asarray(yhat).ravel()
+    return float(np.count_nonzero(yhat) / len(yhat))

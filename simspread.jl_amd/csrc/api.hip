@@ -1111,6 +1111,24 @@ int ss_topl_f32(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, i
   return SS_OK;
 }
 
+int ss_rank_metrics_f32(const uint8_t* y, const float* yhat, int64_t n, double alpha, double out[4], int mem) {
+  SS_API_LOCK();
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (n <= 0) return fail(SS_EINVAL, "rank metrics: n must be positive");
+  if (!y || !yhat || !out) return fail(SS_EINVAL, "rank metrics: NULL buffer");
+  if (!(alpha > 0.0)) return fail(SS_EINVAL, "rank metrics: alpha must be positive");
+  if (mem == SS_MEM_DEVICE) return launch_rank_metrics(y, yhat, n, alpha, out);
+  hipStream_t st = ctx().stream;
+  DevBuf<unsigned char> dy;
+  DevBuf<float> ds;
+  SS_TRY(dy.alloc((size_t)n));
+  SS_TRY(ds.alloc((size_t)n));
+  SS_HIP(hipMemcpyAsync(dy.p, y, (size_t)n, hipMemcpyHostToDevice, st));
+  SS_HIP(hipMemcpyAsync(ds.p, yhat, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+  return launch_rank_metrics(dy.p, ds.p, n, alpha, out);
+}
+
 int ss_spmat_create_csr_f32(int64_t rows, int64_t cols, const int64_t* ptr, const int32_t* idx, const float* val,
                             int index_base, int mem, ss_spmat** out) {
   SS_API_LOCK();

@@ -195,6 +195,8 @@ template <class T>
 int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
 
 int launch_topl(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L, int* oidx, float* oval);
+// metrics.hip: AuROC, AuPRC, BEDROC(alpha), validity ratio of one score vector (device inputs, host outputs)
+int launch_rank_metrics(const unsigned char* y, const float* yhat, int64_t n, double alpha, double* out4);
 
 // ---- dense.hip (fp32 only: fp32-input MFMA)
 int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,

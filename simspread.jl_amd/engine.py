@@ -380,3 +380,26 @@ def topl(scores, L: int):
     val = np.empty((nrows, L), np.float32)
     L_.check(lib.ss_topl_f32(a.ctypes.data, nrows, ncols, ncols, L, idx.ctypes.data, val.ctypes.data, L_.SS_MEM_HOST))
     return idx, val
+
+
+def rank_metrics(y, yhat, alpha: float = 20.0) -> dict:
+    """AuROC, AuPRC, BEDROC(alpha) and the validity ratio of one score vector, computed on the device
+    (src/performance.jl:22-89,558-560).  `y`: labels (non-zero = positive), `yhat`: float32 scores; numpy arrays
+    or contiguous torch CUDA tensors (uint8 / float32) of the same length."""
+    lib = L_.lib()
+    out = (C.c_double * 4)()
+    if _is_torch(yhat):
+        import torch
+        yl = y if (_is_torch(y) and y.dtype == torch.uint8) else (y != 0).to(torch.uint8)
+        yl = yl.contiguous().reshape(-1)
+        sc = yhat.contiguous().reshape(-1)
+        if sc.dtype != torch.float32 or yl.numel() != sc.numel():
+            raise TypeError("yhat must be float32 and as long as y")
+        L_.check(lib.ss_rank_metrics_f32(yl.data_ptr(), sc.data_ptr(), sc.numel(), float(alpha), out, L_.SS_MEM_DEVICE))
+    else:
+        sc = np.ascontiguousarray(np.asarray(yhat).ravel(), dtype=np.float32)
+        yl = np.ascontiguousarray((np.asarray(y).ravel() != 0).astype(np.uint8))
+        if yl.size != sc.size:
+            raise AssertionError("The number of scores must be equal to the number of labels")
+        L_.check(lib.ss_rank_metrics_f32(yl.ctypes.data, sc.ctypes.data, sc.size, float(alpha), out, L_.SS_MEM_HOST))
+    return {"AuROC": out[0], "AuPRC": out[1], "BEDROC": out[2], "validity_ratio": out[3]}
