@@ -78,98 +78,138 @@ struct DenseArgs {
   int64_t ldo;
 };
 
-constexpr int DBM = 128, DBN = 128, DBK = 32, DLD = 132;  // DLD: 16-byte aligned rows for ds_write_b128
+constexpr int DBK = 32;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// block 256 threads = 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32
-template <bool LOO>
+// Workgroup = 256 threads = 4 waves as 2 x 2; a wave owns WM x WN MFMA tiles of 32 x 32, so the workgroup tile
+// is (64*WM) x (64*WN): 128 x 128 (WM = WN = 2, the default) or 256 x 128 (WM = 4).  The raw similarities of
+// K-step k+1 are loaded into registers before the MFMA loop of step k and thresholded / scaled / written to the
+// other LDS buffer after it, so the global latency hides behind the matrix work (80 -> 99 TFLOP/s at 50k).
+template <bool LOO, int WM, int WN>
 __global__ void __launch_bounds__(256) transfer_dense_kernel(DenseArgs a) {
-  __shared__ __align__(16) float As[DBK][DLD];
-  __shared__ __align__(16) float Bs[DBK][DLD];
+  constexpr int TM = 64 * WM, TN = 64 * WN;        // workgroup tile
+  constexpr int LDA = TM + 4, LDB = TN + 4;        // 16-byte aligned LDS rows for ds_write_b128
+  constexpr int ITA = TM / 32, ITB = TN / 32;      // float4 per thread and K-step
+  __shared__ __align__(16) float As[2][DBK][LDA];  // two buffers: step k+1 is parked while step k is still being read
+  __shared__ __align__(16) float Bs[2][DBK][LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * DBM, n0 = (int64_t)blockIdx.x * DBN;
-  f32x16 acc[2][2];
+  const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // staging: 128 x 32 tile = 1024 float4 along m; thread t takes quads t, t+256, t+512, t+768
   const bool a_vec = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
   const bool b_vec = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
-  for (int64_t k0 = 0; k0 < a.K; k0 += DBK) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int qd = tid + it * 256;
-      const int kk = qd >> 5;          // 0..31
-      const int mq = (qd & 31) * 4;    // 0..124
-      const int64_t k = k0 + kk;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < a.K) {
-        const float* pa = a.A + k * a.lda + m0 + mq;
-        const float* pb = a.B + k * a.ldb + n0 + mq;
-        if (a_vec && m0 + mq + 3 < a.M) va = *reinterpret_cast<const float4*>(pa);
-        else {
-          if (m0 + mq + 0 < a.M) va.x = pa[0];
-          if (m0 + mq + 1 < a.M) va.y = pa[1];
-          if (m0 + mq + 2 < a.M) va.z = pa[2];
-          if (m0 + mq + 3 < a.M) va.w = pa[3];
-        }
-        if (b_vec && n0 + mq + 3 < a.N) vb = *reinterpret_cast<const float4*>(pb);
-        else {
-          if (n0 + mq + 0 < a.N) vb.x = pb[0];
-          if (n0 + mq + 1 < a.N) vb.y = pb[1];
-          if (n0 + mq + 2 < a.N) vb.z = pb[2];
-          if (n0 + mq + 3 < a.N) vb.w = pb[3];
-        }
-        const float w = a.inv_k[k];
-        // out-of-range rows were loaded as 0: with alpha <= 0 they must still stay zero
-        va.x = (m0 + mq + 0 < a.M) ? cut_val(va.x, a.alpha, a.weighted) * w : 0.f;
-        va.y = (m0 + mq + 1 < a.M) ? cut_val(va.y, a.alpha, a.weighted) * w : 0.f;
-        va.z = (m0 + mq + 2 < a.M) ? cut_val(va.z, a.alpha, a.weighted) * w : 0.f;
-        va.w = (m0 + mq + 3 < a.M) ? cut_val(va.w, a.alpha, a.weighted) * w : 0.f;
-        vb.x = (n0 + mq + 0 < a.N) ? cut_val(vb.x, a.alpha, a.weighted) : 0.f;
-        vb.y = (n0 + mq + 1 < a.N) ? cut_val(vb.y, a.alpha, a.weighted) : 0.f;
-        vb.z = (n0 + mq + 2 < a.N) ? cut_val(vb.z, a.alpha, a.weighted) : 0.f;
-        vb.w = (n0 + mq + 3 < a.N) ? cut_val(vb.w, a.alpha, a.weighted) : 0.f;
-        if (LOO) {  // the feature named after the query itself is not in the fold's graph
-          const int64_t d = k - (a.row_begin + m0 + mq);
-          if (d == 0) va.x = 0.f;
-          if (d == 1) va.y = 0.f;
-          if (d == 2) va.z = 0.f;
-          if (d == 3) va.w = 0.f;
-        }
+
+  float4 ra[ITA], rb[ITB];
+  float rw[ITA];
+  // raw tile of one operand: thread t takes quads t, t+256, ... of the [DBK][T/4] float4 grid
+  auto load_quad = [&](const float* S, int64_t ld, bool vec, int64_t r0, int64_t rows, int64_t k, int mq)
+                       __attribute__((always_inline)) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < a.K) {
+      const float* p = S + k * ld + r0 + mq;
+      if (vec && r0 + mq + 3 < rows) v = *reinterpret_cast<const float4*>(p);
+      else {
+        if (r0 + mq + 0 < rows) v.x = p[0];
+        if (r0 + mq + 1 < rows) v.y = p[1];
+        if (r0 + mq + 2 < rows) v.z = p[2];
+        if (r0 + mq + 3 < rows) v.w = p[3];
       }
-      *reinterpret_cast<float4*>(&As[kk][mq]) = va;
-      *reinterpret_cast<float4*>(&Bs[kk][mq]) = vb;
     }
-    __syncthreads();
+    return v;
+  };
+  auto load_raw = [&](int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < ITA; ++it) {
+      const int qd = tid + it * 256;
+      const int kk = qd / (TM / 4), mq = (qd % (TM / 4)) * 4;
+      ra[it] = load_quad(a.A, a.lda, a_vec, m0, a.M, k0 + kk, mq);
+      rw[it] = (k0 + kk < a.K) ? a.inv_k[k0 + kk] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < ITB; ++it) {
+      const int qd = tid + it * 256;
+      const int kk = qd / (TN / 4), mq = (qd % (TN / 4)) * 4;
+      rb[it] = load_quad(a.B, a.ldb, b_vec, n0, a.N, k0 + kk, mq);
+    }
+  };
+  // threshold, scale and park the raw registers in LDS (out-of-range rows stay zero also for alpha <= 0)
+  auto store_tiles = [&](int64_t k0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < ITA; ++it) {
+      const int qd = tid + it * 256;
+      const int kk = qd / (TM / 4), mq = (qd % (TM / 4)) * 4;
+      const float w = rw[it];
+      float4 v = ra[it];
+      v.x = (m0 + mq + 0 < a.M) ? cut_val(v.x, a.alpha, a.weighted) * w : 0.f;
+      v.y = (m0 + mq + 1 < a.M) ? cut_val(v.y, a.alpha, a.weighted) * w : 0.f;
+      v.z = (m0 + mq + 2 < a.M) ? cut_val(v.z, a.alpha, a.weighted) * w : 0.f;
+      v.w = (m0 + mq + 3 < a.M) ? cut_val(v.w, a.alpha, a.weighted) * w : 0.f;
+      if (LOO) {  // the feature named after the query itself is not in the fold's graph
+        const int64_t d = (k0 + kk) - (a.row_begin + m0 + mq);
+        if (d == 0) v.x = 0.f;
+        if (d == 1) v.y = 0.f;
+        if (d == 2) v.z = 0.f;
+        if (d == 3) v.w = 0.f;
+      }
+      *reinterpret_cast<float4*>(&As[buf][kk][mq]) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < ITB; ++it) {
+      const int qd = tid + it * 256;
+      const int kk = qd / (TN / 4), mq = (qd % (TN / 4)) * 4;
+      float4 v = rb[it];
+      v.x = (n0 + mq + 0 < a.N) ? cut_val(v.x, a.alpha, a.weighted) : 0.f;
+      v.y = (n0 + mq + 1 < a.N) ? cut_val(v.y, a.alpha, a.weighted) : 0.f;
+      v.z = (n0 + mq + 2 < a.N) ? cut_val(v.z, a.alpha, a.weighted) : 0.f;
+      v.w = (n0 + mq + 3 < a.N) ? cut_val(v.w, a.alpha, a.weighted) : 0.f;
+      *reinterpret_cast<float4*>(&Bs[buf][kk][mq]) = v;
+    }
+  };
+
+  // one barrier per K-step: while a wave multiplies out of buffer `cur`, the raw registers of the next step
+  // (loaded during the previous MFMA loop) are thresholded and parked in the other buffer, which nobody reads
+  load_raw(0);
+  store_tiles(0, 0);
+  __syncthreads();
+  if (DBK < a.K) load_raw(DBK);
+  int cur = 0;
+  for (int64_t k0 = 0; k0 < a.K; k0 += DBK) {
 #pragma unroll
     for (int kk = 0; kk < DBK; kk += 2) {
       const int kr = kk + (lane >> 5);
       const int c = lane & 31;
-      const float a0 = As[kr][wm * 64 + c], a1 = As[kr][wm * 64 + 32 + c];
-      const float b0 = Bs[kr][wn * 64 + c], b1 = Bs[kr][wn * 64 + 32 + c];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float av[WM], bv[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) av[i] = As[cur][kr][wm * (32 * WM) + i * 32 + c];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bv[j] = Bs[cur][kr][wn * (32 * WN) + j * 32 + c];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
+    if (k0 + DBK < a.K) store_tiles(k0 + DBK, cur ^ 1);
     __syncthreads();
+    if (k0 + 2 * DBK < a.K) load_raw(k0 + 2 * DBK);  // in flight during the next MFMA loop
+    cur ^= 1;
   }
   // C/D layout of 32x32 f32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < WN; ++j) {
+      const int64_t n = n0 + wn * (32 * WN) + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t m = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < a.M && n < a.N) {
           float z;
           if (LOO) {
@@ -205,9 +245,18 @@ int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k
   a.weighted = d.weighted ? 1 : 0;
   a.out = out;
   a.ldo = ldo;
-  dim3 grid((unsigned)ceil_div(d.ns, DBN), (unsigned)ceil_div(nrows, DBM));
-  if (loo) hipLaunchKernelGGL(transfer_dense_kernel<true>, grid, dim3(256), 0, ctx().stream, a);
-  else hipLaunchKernelGGL(transfer_dense_kernel<false>, grid, dim3(256), 0, ctx().stream, a);
+  // 128 x 128 tiles (2 waves per SIMD).  SS_DENSE_TILE=256 selects the 256 x 128 variant: less L2 traffic per flop
+  // but 128 accumulator + 200 other registers leave one wave per SIMD -- measured 87 vs 99 TFLOP/s at 50k
+  int tm = 128;
+  if (const char* e = getenv("SS_DENSE_TILE")) tm = atoi(e) == 256 ? 256 : 128;
+  dim3 grid((unsigned)ceil_div(d.ns, 128), (unsigned)ceil_div(nrows, tm));
+  if (tm == 256) {
+    if (loo) hipLaunchKernelGGL((transfer_dense_kernel<true, 4, 2>), grid, dim3(256), 0, ctx().stream, a);
+    else hipLaunchKernelGGL((transfer_dense_kernel<false, 4, 2>), grid, dim3(256), 0, ctx().stream, a);
+  } else {
+    if (loo) hipLaunchKernelGGL((transfer_dense_kernel<true, 2, 2>), grid, dim3(256), 0, ctx().stream, a);
+    else hipLaunchKernelGGL((transfer_dense_kernel<false, 2, 2>), grid, dim3(256), 0, ctx().stream, a);
+  }
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
