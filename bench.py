@@ -148,15 +148,17 @@ def bench_c3loo(args, ss, torch, dist, world, rank):
     for _ in range(args.warmup):
         g.predict_loo(pos, pos + folds, clean=True, out=out)
     barrier()
+    ss.timing_hold(True)   # HIP-event stage timings add up over the timed region, read once after it
     t0 = time.perf_counter()
-    st = {"transfer_ms": [], "spmm_ms": []}
     for i in range(args.steps):
         b = lo + (i * folds) % max(1, (hi - lo) - folds + 1)
         g.predict_loo(b, b + folds, clean=True, out=out)
-        t = ss.timing_last()
-        st["transfer_ms"].append(t["transfer_ms"]); st["spmm_ms"].append(t["spmm_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
+    t = ss.timing_last()
+    ss.timing_hold(False)
+    st = {"transfer_ms": [t["transfer_ms"] / max(1, t["transfer_launches"])],
+          "spmm_ms": [t["spmm_ms"] / max(1, t["spmm_launches"])]}
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -244,15 +246,17 @@ def main():
     for _ in range(args.warmup):
         g.predict("query", out=scores)
     barrier()
+    ss.timing_hold(True)   # HIP-event stage timings add up over the timed region, read once after it
     t0 = time.perf_counter()
-    stage = {"transfer_ms": [], "spmm_ms": [], "total_ms": []}
     for _ in range(args.steps):
-        g.predict("query", out=scores)
-        t = ss.timing_last()
-        for k_ in stage:
-            stage[k_].append(t[k_])
+        g.predict("query", out=scores)   # enqueued in stream order; the barrier below waits for all K steps
     barrier()
     elapsed = time.perf_counter() - t0
+    t = ss.timing_last()
+    ss.timing_hold(False)
+    # average duration of one launch of each kernel over the timed region (one launch per stage and step here)
+    stage = {"transfer_ms": [t["transfer_ms"] / max(1, t["transfer_launches"])],
+             "spmm_ms": [t["spmm_ms"] / max(1, t["spmm_launches"])], "total_ms": [t["total_ms"] / args.steps]}
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)

@@ -78,6 +78,10 @@ int ss_synchronize(void);
  * (stage 2), [3] epilogues/transposes, [4] host->device, [5] device->host,
  * [6] number of SpMM launches, [7] number of stage-1 launches.  Writes min(n,8) values. */
 int ss_timing_last(double* ms, int n);
+/* enable != 0: from now on the timings of successive calls add up (ss_timing_last returns the sums and launch
+ * counts since the hold began) instead of replacing one another, so that a benchmark loop need not stop after
+ * every call to read them; enable == 0: back to per-call timings. */
+int ss_timing_hold(int enable);
 
 /* ------------------------------------------------------- cutoff / k / spread -- */
 /* cutoff(X, alpha, weighted): out = x >= alpha ? (weighted ? x : 1) : 0, element-wise
@@ -163,7 +167,10 @@ int ss_graph_degrees(const ss_graph* g, int64_t* kf, int64_t* ks, int64_t* kt);
  * (SS_ROWS_QUERY) or of the source nodes (SS_ROWS_SOURCE; feature path + target path,
  * which is also what the 3-layer predict(A, ytrain) returns) and all nt targets.
  * clean != 0 fuses clean! (src/core.jl:478-484): column t becomes -99 when target t
- * has no edge in A.  out holds (row_end-row_begin) x nt scores in `layout`. */
+ * has no edge in A.  out holds (row_end-row_begin) x nt scores in `layout`.
+ * With mem == SS_MEM_DEVICE and SS_LAYOUT_ROWMAJOR the kernels write straight into `out` and the call returns
+ * once they are enqueued (stream order, like a kernel launch): work queued later on the same stream sees the
+ * scores, anything else waits with ss_synchronize().  Every other combination returns with `out` complete. */
 int ss_predict_f32(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean,
                    float* out, int64_t ld, int layout, int mem);
 int ss_predict_f64(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean,

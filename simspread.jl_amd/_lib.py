@@ -47,6 +47,7 @@ def _sigs():
         "ss_reset_stream": ([], _int),
         "ss_synchronize": ([], _int),
         "ss_timing_last": ([_vp, _int], _int),
+        "ss_timing_hold": ([_int], _int),
         "ss_graph_destroy": ([_vp], _int),
         "ss_graph_info": ([_vp, _vp], _int),
         "ss_graph_degrees": ([_vp, _vp, _vp, _vp], _int),
@@ -128,6 +129,12 @@ def use_torch_stream():
     pointer, so that the kernels that produced them are ordered before the library's."""
     import torch
     check(lib().ss_set_stream(torch.cuda.current_stream().cuda_stream))
+
+
+def timing_hold(enable: bool = True) -> None:
+    """Let the stage timings of successive calls add up (read the sums with timing_last) instead of replacing one
+    another, so that a loop of predictions need not stop after every call."""
+    check(lib().ss_timing_hold(1 if enable else 0))
 
 
 def timing_last():

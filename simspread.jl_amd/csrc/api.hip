@@ -38,6 +38,8 @@ int require_init() {
 
 void timing_begin_call() {
   Timing& t = ctx().timing;
+  t.dirty = true;
+  if (t.hold) return;  // accumulate: the spans of this call join those already recorded
   t.used = 0;
   t.spans.clear();
   for (double& e : t.extra) e = 0;
@@ -489,8 +491,11 @@ static int predict_impl(ss_graph* h, int kind, int64_t row_begin, int64_t row_en
     }
     t5.stop();
   }
-  // temporaries (transfer block, staging) are released on return: wait for the stream
-  SS_HIP(hipStreamSynchronize(st));
+  // Staging buffers are released on return and host results must be complete: wait for the stream.  With the
+  // scores written straight into the caller's device buffer there is nothing to release (the transfer block
+  // lives in the handle), so the call returns as soon as the work is enqueued -- stream order, like a kernel
+  // launch; ss_synchronize() or the caller's own stream synchronisation waits for it.
+  if (!direct) SS_HIP(hipStreamSynchronize(st));
   return SS_OK;
 }
 
@@ -897,6 +902,18 @@ int ss_synchronize(void) {
   SS_API_LOCK();
   SS_TRY(require_init());
   SS_HIP(hipStreamSynchronize(ctx().stream));
+  return SS_OK;
+}
+
+int ss_timing_hold(int enable) {
+  SS_API_LOCK();
+  SS_TRY(require_init());
+  Timing& t = ctx().timing;
+  t.hold = false;
+  if (enable) {
+    timing_begin_call();  // start from zero
+    t.hold = true;
+  }
   return SS_OK;
 }
 

@@ -44,6 +44,7 @@ struct Timing {
   double extra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double resolved[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool dirty = false;
+  bool hold = false;  // ss_timing_hold: calls accumulate instead of replacing one another
 };
 
 struct Ctx {
