@@ -441,6 +441,16 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
       T acc[QT];
 #pragma unroll
       for (int q = 0; q < QT; ++q) acc[q] = T(0);
+      // chunks after the first add to what is already in F: request those values now, they are needed only
+      // after the gathers of this slice (otherwise every slice ends on an exposed global-load latency)
+      const int64_t m = (int64_t)s * 64 + lane;
+      T fprev[QT];
+#pragma unroll
+      for (int q = 0; q < QT; ++q) {
+        fprev[q] = T(0);
+        if (c && m < a.M && b0 + q < a.B)
+          fprev[q] = a.F[(a.out_rows ? (int64_t)a.out_rows[b0 + q] : b0 + q) * a.ldf + m];
+      }
       const ushort4* ip = reinterpret_cast<const ushort4*>(a.idx) + (int64_t)o * 64 + lane;
       const Vec<T, 4>* vp = reinterpret_cast<const Vec<T, 4>*>(a.val) + (int64_t)o * 64 + lane;
       // NB quads of indices (and values) are fetched ahead of the LDS gathers they feed: the index
@@ -496,15 +506,13 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
           gather(ib, wb);
         }
       }
-      const int64_t m = (int64_t)s * 64 + lane;
       if (m < a.M) {
         const bool flag = last && a.clean_deg != nullptr && a.clean_deg[m] == 0;
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
           if (b0 + q < a.B) {
             T* f = a.F + (a.out_rows ? (int64_t)a.out_rows[b0 + q] : b0 + q) * a.ldf + m;
-            T r = acc[q];
-            if (c) r += *f;
+            const T r = acc[q] + fprev[q];
             *f = flag ? T(-99) : r;
           }
         }
