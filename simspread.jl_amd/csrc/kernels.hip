@@ -418,6 +418,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
   V* tile = reinterpret_cast<V*>(smem_raw);  // [KC + 1]; entry KC stays zero (padding target)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int64_t b0 = (int64_t)blockIdx.x * QT;
+  if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();
 
   for (int c = 0; c < a.nchunks; ++c) {
     const int64_t k0 = (int64_t)c * a.KC;
@@ -475,14 +476,24 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
         }
       };
       auto gather = [&](const uint2 (&iq)[SELL_NB], const Vec<T, 4> (&wq)[SELL_NB]) {
-        const char* tb = reinterpret_cast<const char*>(tile);
+        // LDS address of tile[k] = k * 16: one SDWA shift per 16-bit index, used as the address itself (the tile
+        // is the only LDS object of this kernel and starts at LDS address 0 -- checked once at kernel entry;
+        // going through the generic tile pointer costs one more VALU add per non-zero)
+        typedef T NV __attribute__((ext_vector_type(QT)));
+        using LV = const __attribute__((address_space(3))) NV*;
+        auto row = [](unsigned addr) __attribute__((always_inline)) {
+          const NV n = *(LV)(uintptr_t)addr;
+          V r;
+#pragma unroll
+          for (int q = 0; q < QT; ++q) r.v[q] = n[q];
+          return r;
+        };
 #pragma unroll
         for (int j = 0; j < SELL_NB; ++j) {
-          // byte offset of tile[k] = k * 16: one SDWA shift per 16-bit index
-          const V t0 = *reinterpret_cast<const V*>(tb + half_shl<0>(iq[j].x, TSH));
-          const V t1 = *reinterpret_cast<const V*>(tb + half_shl<1>(iq[j].x, TSH));
-          const V t2 = *reinterpret_cast<const V*>(tb + half_shl<0>(iq[j].y, TSH));
-          const V t3 = *reinterpret_cast<const V*>(tb + half_shl<1>(iq[j].y, TSH));
+          const V t0 = row(half_shl<0>(iq[j].x, TSH));
+          const V t1 = row(half_shl<1>(iq[j].x, TSH));
+          const V t2 = row(half_shl<0>(iq[j].y, TSH));
+          const V t3 = row(half_shl<1>(iq[j].y, TSH));
           if (BIN) {
 #pragma unroll
             for (int q = 0; q < QT; ++q) acc[q] += (t0.v[q] + t1.v[q]) + (t2.v[q] + t3.v[q]);
