@@ -420,7 +420,8 @@ __global__ void sell_width_kernel(const int* __restrict__ ptr, const int* __rest
     n = a - first;
   }
   for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(n, o); n = t > n ? t : n; }
-  if (lane == 0) widthq[wave] = (n + 3) >> 2;
+  // in quads, rounded up to whole groups of four: the SpMM kernel fetches and consumes four quads at a time
+  if (lane == 0) widthq[wave] = (((n + 3) >> 2) + 3) & ~3;
 }
 
 template <class T>
@@ -625,7 +626,8 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   // padded storage well above nnz means skewed row lengths inside slices: split the longest rows into
   // virtual rows of bounded length and sort all (virtual) rows by length before cutting slices
   const char* force = getenv("SS_SELL_SORT");
-  const bool want_sort = force ? atoi(force) != 0 : ((double)nq * 256.0 > 1.3 * (double)in.nnz + 65536.0);
+  // (the rounding of every slice to whole groups of four quads adds ~1.5 quads per slice and is not skew)
+  const bool want_sort = force ? atoi(force) != 0 : (((double)nq - 1.5 * (double)nws) * 256.0 > 1.3 * (double)in.nnz + 65536.0);
   if (want_sort && in.rows > 64) {
     int64_t lmax = in.nnz / 4096;  // a slice of full-length virtual rows is ~1/4 of one wave's share of a workgroup
     if (const char* e = getenv("SS_SELL_LMAX")) lmax = atoll(e);
@@ -677,9 +679,16 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   const int64_t nws_f = (int64_t)out.nslices * out.nchunks;
   if (nq < 0 || (int64_t)nq * 256 >= (1LL << 40)) return fail(SS_EUNSUPPORTED, "SELL storage too large");
   out.nquads = nq;
-  SS_TRY(out.idx.alloc((size_t)nq * 256));
-  if (!out.binary) SS_TRY(out.val.alloc((size_t)nq * 256));
-  else out.val.release();
+  // two groups of four quads of slack: the SpMM kernel loads (and ignores) up to that much past the last slice
+  const size_t slack = 8 * 256;
+  SS_TRY(out.idx.alloc((size_t)nq * 256 + slack));
+  SS_HIP(hipMemsetAsync(out.idx.p + (size_t)nq * 256, 0, slack * sizeof(unsigned short), st));
+  if (!out.binary) {
+    SS_TRY(out.val.alloc((size_t)nq * 256 + slack));
+    SS_HIP(hipMemsetAsync(out.val.p + (size_t)nq * 256, 0, slack * sizeof(T), st));
+  } else {
+    out.val.release();
+  }
   if (getenv("SS_SELL_PLAIN")) {
     hipLaunchKernelGGL(sell_fill_kernel<T>, dim3((unsigned)ceil_div(nws_f * 64, 256)), dim3(256), 0, st, in.ptr.p,
                        in.idx.p, in.val.p, out.vrows, out.KC, out.nslices, out.nchunks, out.off.p,

@@ -454,28 +454,24 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
       }
       const ushort4* ip = reinterpret_cast<const ushort4*>(a.idx) + (int64_t)o * 64 + lane;
       const Vec<T, 4>* vp = reinterpret_cast<const Vec<T, 4>*>(a.val) + (int64_t)o * 64 + lane;
-      // NB quads of indices (and values) are fetched ahead of the LDS gathers they feed: the index
-      // stream comes from L2 at several hundred cycles per access, the loop must not wait per quad.
-      // Loads are unconditional (clamped) and the pad is a select: branches around loads make hipcc
-      // wait vmcnt(0) per batch.  Two register sets (A/B) alternate so that nothing is copied.
+      // NB quads of indices (and values) are fetched ahead of the LDS gathers they feed: the index stream comes
+      // from L2 at several hundred cycles per access, the loop must not wait per quad.  The builder pads every
+      // slice to whole groups of NB quads and leaves two groups of slack behind the last slice, so the loads need
+      // neither clamps nor pad selects nor branches: with branches around them hipcc waits vmcnt(0) right after
+      // issuing the next group, i.e. nothing would be in flight while the current group is gathered.  The group
+      // past the end of a slice is loaded and never used.  Two register sets (A/B) alternate, nothing is copied.
       const uint2* ipw = reinterpret_cast<const uint2*>(ip);
       const int nq = oe - o;
-      const int qlast = nq > 0 ? nq - 1 : 0;
-      const uint2 padw = make_uint2(((unsigned)a.KC << 16) | (unsigned)a.KC, ((unsigned)a.KC << 16) | (unsigned)a.KC);
       uint2 ia[SELL_NB], ib[SELL_NB];
       Vec<T, 4> wa[SELL_NB], wb[SELL_NB];
-      auto fetch = [&](uint2 (&iq)[SELL_NB], Vec<T, 4> (&wq)[SELL_NB], int base) {
+      auto fetch = [&](uint2 (&iq)[SELL_NB], Vec<T, 4> (&wq)[SELL_NB], int base) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < SELL_NB; ++j) {
-          const int x = base + j;
-          const int xc = x < qlast ? x : qlast;
-          const uint2 li = ipw[(int64_t)xc * 64];
-          iq[j].x = x < nq ? li.x : padw.x;
-          iq[j].y = x < nq ? li.y : padw.y;
-          if (!BIN) wq[j] = vp[(int64_t)xc * 64];  // a padded index reads the zero tile row: any weight is fine
+          iq[j] = ipw[(int64_t)(base + j) * 64];
+          if (!BIN) wq[j] = vp[(int64_t)(base + j) * 64];
         }
       };
-      auto gather = [&](const uint2 (&iq)[SELL_NB], const Vec<T, 4> (&wq)[SELL_NB]) {
+      auto gather = [&](const uint2 (&iq)[SELL_NB], const Vec<T, 4> (&wq)[SELL_NB]) __attribute__((always_inline)) {
         // LDS address of tile[k] = k * 16: one SDWA shift per 16-bit index, used as the address itself (the tile
         // is the only LDS object of this kernel and starts at LDS address 0 -- checked once at kernel entry;
         // going through the generic tile pointer costs one more VALU add per non-zero)
@@ -508,15 +504,17 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
           }
         }
       };
+      // (both gathers of the loop body are unconditional on purpose: a gather under `if` lets the compiler sink
+      // its loads into the branch, right in front of their use)
       fetch(ia, wa, 0);
-      for (int u = 0; u < nq; u += 2 * SELL_NB) {
+      int u = 0;
+      for (; u + 2 * SELL_NB <= nq; u += 2 * SELL_NB) {
         fetch(ib, wb, u + SELL_NB);
         gather(ia, wa);
-        if (u + SELL_NB < nq) {
-          fetch(ia, wa, u + 2 * SELL_NB);
-          gather(ib, wb);
-        }
+        fetch(ia, wa, u + 2 * SELL_NB);
+        gather(ib, wb);
       }
+      if (u < nq) gather(ia, wa);  // odd number of groups: the last one is already here
       if (m < a.M) {
         const bool flag = last && a.clean_deg != nullptr && a.clean_deg[m] == 0;
 #pragma unroll
