@@ -696,9 +696,14 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   // (SS_NARROW_REGACC=1) and 5.6 ms for gathering rows of R from L2 (SS_NARROW_CSR=1))
   int wide_from = 9;
   if (const char* e = getenv("SS_WIDE_FROM")) wide_from = atoi(e);
-  // 8 < B <= 32 (fp64: 16), row-major: row-block kernel (spmm_mid.hip): W streamed once, no partial sums.
-  // Measured at 100k x 100k / 1 %: B=16 0.37 ms (wide kernel 0.56), B=32 0.74 (1.03); SS_MID=0: wide kernel
-  const bool mid = (B > 8 && B * (int64_t)sizeof(T) <= 128 && r_layout == SS_LAYOUT_ROWMAJOR &&
+  // 8 <= B <= 32 (fp64: 8 < B <= 16), row-major: row-block kernel (spmm_mid.hip): W streamed once, no partial
+  // sums.  Measured at 100k x 100k / 1 %: B=8 0.23 ms (narrow kernel 0.33), B=16 0.37 ms (wide kernel 0.56),
+  // B=32 0.74 (1.03); SS_MID=0: the other kernels
+  // fp32: 32-byte tile rows serve B = 8 (0.23 ms vs 0.33 ms narrow); B = 5..7 cannot be staged in 16-byte pieces
+  // and are no faster than the narrow kernel
+  int mid_from = sizeof(T) == 4 ? 8 : 9;
+  if (const char* e = getenv("SS_MID_FROM")) mid_from = atoi(e);
+  const bool mid = (B >= mid_from && B * (int64_t)sizeof(T) <= 128 && r_layout == SS_LAYOUT_ROWMAJOR &&
                     f_layout == SS_LAYOUT_ROWMAJOR && !(getenv("SS_MID") && atoi(getenv("SS_MID")) == 0) &&
                     getenv("SS_WIDE_FROM") == nullptr && getenv("SS_NARROW_REGACC") == nullptr &&
                     getenv("SS_NARROW_CSR") == nullptr);
@@ -707,8 +712,10 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   DevBuf<T> Rt, Ft;
   const bool use_csr_gather = getenv("SS_NARROW_CSR") != nullptr;
   if (mid) {
-    const int slot = (B <= 16 && sizeof(T) == 4) ? 0 : 1;  // 64-byte tile rows (16 floats) or 128-byte (32 floats, 16 doubles)
-    const int bv = (slot == 0 ? 64 : 128) / (int)sizeof(T);
+    // 32-byte tile rows (8 floats), 64-byte (16 floats) or 128-byte (32 floats, 16 doubles)
+    const int rowb = (B * (int64_t)sizeof(T) <= 32 && sizeof(T) == 4) ? 32 : ((B <= 16 && sizeof(T) == 4) ? 64 : 128);
+    const int slot = rowb == 32 ? 2 : (rowb == 64 ? 0 : 1);
+    const int bv = rowb / (int)sizeof(T);
     DevChunked<T>& op = m.mid[slot];
     if (op.SC == 0) {
       int kc = mid_chunk_cols<T>(bv);

@@ -108,7 +108,7 @@ struct SpMat {
   DevSell<T> sell;
   int sell_qt = 0;
   DevChunked<T> narrow[5];  // quad-aligned chunked operands for B <= 1, 2, 4, 8, 16 (built lazily)
-  DevChunked<T> mid[2];     // operands of the mid-width kernel: 64- and 128-byte tile rows (built lazily)
+  DevChunked<T> mid[3];     // operands of the mid-width kernel: 64-, 128- and 32-byte tile rows (built lazily)
   DevPairs pairs;           // operand of the register-accumulator kernel (16 < B <= 64, fp32)
   DevBuf<T> partial;        // [nchunks][rows][BV] partial sums of the narrow kernel
 };

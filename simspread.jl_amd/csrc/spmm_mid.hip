@@ -1,4 +1,4 @@
-// Stage 2, mid width (8 < B <= 32 columns of R; fp64: <= 16): F = W*R with the accumulators of a block of rows
+// Stage 2, mid width (8 <= B <= 32 columns of R; fp64: 8 < B <= 16): F = W*R with the accumulators of a block of rows
 // held in registers while the row chunks of R cycle through LDS.
 //
 // The narrow kernel (kernels.hip, spmm_chunked_narrow_kernel) keeps one chunk of R per workgroup and writes
@@ -60,11 +60,11 @@ struct alignas(16) Pack {
 template <class T, int BV, int GL, int UR>
 __global__ void __launch_bounds__(MID_THREADS) spmm_rowblock_kernel(MidArgs<T> a) {
   constexpr int PW = 16 / (int)sizeof(T);          // values per 16-byte slot
-  constexpr int NCG = BV / PW;                     // slots per tile row (4 or 8)
+  constexpr int NCG = BV / PW;                     // slots per tile row (2, 4 or 8)
   constexpr int RPL = 16 / NCG;                    // tile rows per 256-byte LDS line
-  constexpr int RSH = RPL == 4 ? 2 : (RPL == 2 ? 1 : 0);
+  constexpr int RSH = RPL == 8 ? 3 : (RPL == 4 ? 2 : (RPL == 2 ? 1 : 0));
   constexpr int ROWB = BV * (int)sizeof(T);        // bytes per tile row
-  static_assert(NCG == 4 || NCG == 8 || NCG == 16, "tile row must be 64, 128 or 256 bytes");
+  static_assert(NCG == 2 || NCG == 4 || NCG == 8 || NCG == 16, "tile row must be 32, 64, 128 or 256 bytes");
   using P = Pack<T, PW>;
   using Q = Pack<T, 4>;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -218,7 +218,7 @@ template <class T, int BV>
 static int launch_mid_bv(MidArgs<T>& a, size_t lds, double mean_quads) {
   // accumulators per lane = UR*BV values (112..128 registers) next to the prefetched first quads; with one
   // workgroup per CU a group of GL lanes must hold ceil(M / (256 * 512/GL)) rows
-  constexpr int UR = (BV * sizeof(T) == 64) ? 7 : 4;
+  constexpr int UR = (BV * sizeof(T) == 32) ? 13 : ((BV * sizeof(T) == 64) ? 7 : 4);
   if (mean_quads > 24.0) return launch_mid_variant<T, BV, 64, UR>(a, lds);
   if (mean_quads > 12.0) return launch_mid_variant<T, BV, 16, UR>(a, lds);
   if (mean_quads > 5.0) return launch_mid_variant<T, BV, 8, UR>(a, lds);
@@ -242,6 +242,7 @@ int launch_spmm_rowblock(const DevChunked<T>& W, int bv, const T* R, int64_t ldr
   const double mean_quads = (double)W.stored / 4.0 / ((double)W.rows * (double)W.nchunks);
   if constexpr (sizeof(T) == 4) {
     switch (bv) {
+      case 8: return launch_mid_bv<T, 8>(a, lds, mean_quads);
       case 16: return launch_mid_bv<T, 16>(a, lds, mean_quads);
       case 32: return launch_mid_bv<T, 32>(a, lds, mean_quads);
     }
