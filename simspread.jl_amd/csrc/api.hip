@@ -374,8 +374,15 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
       if (g.dense.on) {
         if constexpr (std::is_same<T, float>::value) {
           const bool loo = (kind == 2);
-          SS_TRY(launch_transfer_dense(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
-                                       row_begin + r0, nb, Tbuf.p, nj));
+          // default: bf16 matrix cores on exact bf16 planes of the operands (dense_bf16.hip: 1.5x weighted, 3.2x
+          // unweighted at 50k); SS_DENSE_BF16=0: the fp32-input MFMA kernel of dense.hip
+          const bool use_bf16 = !(getenv("SS_DENSE_BF16") && atoi(getenv("SS_DENSE_BF16")) == 0);
+          if (use_bf16)
+            SS_TRY(launch_transfer_dense_bf16(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
+                                              row_begin + r0, nb, Tbuf.p, nj));
+          else
+            SS_TRY(launch_transfer_dense(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
+                                         row_begin + r0, nb, Tbuf.p, nj));
         } else {
           return fail(SS_EUNSUPPORTED, "the dense-similarity path is fp32 only");
         }

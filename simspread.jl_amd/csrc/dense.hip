@@ -76,6 +76,7 @@ struct DenseArgs {
   int weighted;
   float* out;          // T, row-major M x N
   int64_t ldo;
+  int gx, gy;          // column / row blocks of the launch
 };
 
 constexpr int DBK = 32;
@@ -95,7 +96,18 @@ __global__ void __launch_bounds__(256) transfer_dense_kernel(DenseArgs a) {
   __shared__ __align__(16) float Bs[2][DBK][LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
+  // tile order: all row blocks of a group of 16 column blocks before the next group (the workgroups in flight then
+  // share gy + 16 operand tiles per K-step instead of 1 + gx: the source operand is not re-streamed per row block)
+  int bm, bn;
+  {
+    const int gy = a.gy, GW = 16;
+    const int id = (int)blockIdx.x;
+    const int grp = id / (gy * GW);
+    const int local = id - grp * gy * GW;
+    bm = local % gy;
+    bn = grp * GW + local / gy;
+  }
+  const int64_t m0 = (int64_t)bm * TM, n0 = (int64_t)bn * TN;
   f32x16 acc[WM][WN];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
@@ -249,7 +261,9 @@ int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k
   // but 128 accumulator + 200 other registers leave one wave per SIMD -- measured 87 vs 99 TFLOP/s at 50k
   int tm = 128;
   if (const char* e = getenv("SS_DENSE_TILE")) tm = atoi(e) == 256 ? 256 : 128;
-  dim3 grid((unsigned)ceil_div(d.ns, 128), (unsigned)ceil_div(nrows, tm));
+  a.gx = (int)ceil_div(d.ns, 128);
+  a.gy = (int)ceil_div(nrows, tm);
+  dim3 grid((unsigned)(a.gx * a.gy));
   if (tm == 256) {
     if (loo) hipLaunchKernelGGL((transfer_dense_kernel<true, 4, 2>), grid, dim3(256), 0, ctx().stream, a);
     else hipLaunchKernelGGL((transfer_dense_kernel<false, 4, 2>), grid, dim3(256), 0, ctx().stream, a);

@@ -70,6 +70,10 @@ struct DenseSim {
   bool weighted = true;
   DevBuf<T> Sq, Ss;       // nq x nf and ns x nf, column-major, ld = rows
   DevBuf<T> inv_kf_m1;    // 1/(kf-1): leave-one-out coefficient
+  // bf16 planes of the thresholded operands (dense_bf16.hip): source side once per graph, query side per row block
+  DevBuf<unsigned short> Bpl, Apl;
+  int Bpl_np = 0;
+  int64_t Bpl_Np = 0, Bpl_Kp = 0;
 };
 
 template <class T>
@@ -202,6 +206,9 @@ int launch_rank_metrics(const unsigned char* y, const float* yhat, int64_t n, do
 int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
                           int64_t row_begin, int64_t nrows, float* out, int64_t ldo);
 int dense_degrees(Graph<float>& g);
+// dense_bf16.hip: the same product on the bf16 matrix cores with the operands split into exact bf16 planes
+int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
+                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo);
 
 template <class T>
 int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout);
