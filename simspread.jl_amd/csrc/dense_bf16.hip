@@ -202,13 +202,162 @@ __global__ void __launch_bounds__(256) transfer_dense_bf16_kernel(DenseBf16Args 
     }
 }
 
+// ------------------------------------------------------------------ the GEMM, three-stage ring
+// The kernel above requests a tile while the previous one is multiplied (512 cycles per wave), which is less than
+// the L2 latency, so it lives off the second workgroup of the CU.  Here one workgroup per CU (8 waves as 4 x 2,
+// 256 x TN tile, wave tile 64 x TN/2) keeps a ring of NST stages in LDS with NST - 1 K-steps in flight; with the
+// default 256 x 256 x 64 and two stages a K-step is 1024 MFMA cycles per wave, two waves per SIMD.  The LDS-DMA is
+// written as inline assembly so that the compiler does not drain it (s_waitcnt vmcnt(0)) in front of every ds_read;
+// completion is awaited with a counted s_waitcnt vmcnt(N) and one barrier per K-step.
+__device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base) : "memory");
+}
+
+constexpr int RING_TM = 256;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// TN: tile columns (128 or 256), BK: K per stage (32 or 64), NST: stages in the ring (NST - 1 in flight)
+template <bool LOO, int TN, int BK, int NST>
+__global__ void __launch_bounds__(512) transfer_dense_bf16_ring_kernel(DenseBf16Args a) {
+  constexpr int SLOTS = BK / 8, ROWB = BK * 2;          // 16-byte slots / bytes per tile row
+  constexpr int A_BYTES = RING_TM * ROWB, B_BYTES = TN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int NA = RING_TM * SLOTS / 512, NB = TN * SLOTS / 512, NDMA = NA + NB;  // DMA instructions per thread, stage
+  constexpr int WN = TN / 64;                           // 32-column MFMA tiles per wave (wave tile 64 x TN/2)
+  static_assert((NST - 2) * NDMA <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __align__(16) unsigned char ring[];
+  const unsigned ring0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves
+  int bm, bn;
+  {
+    const int gy = a.gy, GW = (TN == 128) ? 16 : 8;
+    const int id = (int)blockIdx.x;
+    const int grp = id / (gy * GW);
+    const int local = id - grp * gy * GW;
+    bm = local % gy;
+    bn = grp * GW + local / gy;
+  }
+  const int64_t m0 = (int64_t)bm * RING_TM, n0 = (int64_t)bn * TN;
+  f32x16b acc[2][WN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int ksteps = (int)(a.Kp / BK);
+  const int total = a.npairs * ksteps;
+  auto swz = [](int row) __attribute__((always_inline)) { return SLOTS == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+
+  auto stage = [&](int step) __attribute__((always_inline)) {
+    const int pair = step / ksteps, kt = step - pair * ksteps;
+    const unsigned short* Ap = a.A + (int64_t)a.pa[pair] * a.a_plane + m0 * a.Kp + (int64_t)kt * BK;
+    const unsigned short* Bp = a.B + (int64_t)a.pb[pair] * a.b_plane + n0 * a.Kp + (int64_t)kt * BK;
+    const unsigned base = ring0 + (unsigned)(step % NST) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int p0 = wave * (64 * NA) + i * 64;
+      const int p = p0 + lane;
+      const int row = p / SLOTS, c = (p % SLOTS) ^ swz(row);
+      lds_dma16(Ap + (int64_t)row * a.Kp + 8 * c, __builtin_amdgcn_readfirstlane(base + (unsigned)p0 * 16u));
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int p0 = wave * (64 * NB) + i * 64;
+      const int p = p0 + lane;
+      const int row = p / SLOTS, c = (p % SLOTS) ^ swz(row);
+      lds_dma16(Bp + (int64_t)row * a.Kp + 8 * c, __builtin_amdgcn_readfirstlane(base + (unsigned)A_BYTES + (unsigned)p0 * 16u));
+    }
+  };
+
+  const int r = lane & 31, h = lane >> 5;
+  auto frag = [&](const unsigned char* tile, int row, int c) __attribute__((always_inline)) {
+    return *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((c ^ swz(row)) << 4));
+  };
+
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < total) stage(s0);
+  for (int step = 0; step < total; ++step) {
+    // my pieces of stage `step` have landed when only the stages after it are still in flight
+    const int after = total - 1 - step;
+    if (after >= NST - 2) wait_vmcnt<(NST - 2) * NDMA>();
+    else if (NST > 3 && after == 1) wait_vmcnt<NDMA>();
+    else wait_vmcnt<0>();
+    __syncthreads();  // ... and everybody's; everybody is also done with stage step-1, whose slot is refilled now
+    if (step + NST - 1 < total) stage(step + NST - 1);
+    const unsigned char* At = ring + (step % NST) * STAGE_BYTES;
+    const unsigned char* Bt = At + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int c = 2 * s + h;
+      bf16x8 af[2], bfr[WN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = frag(At, wm * 64 + i * 32 + r, c);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bfr[j] = frag(Bt, wn * (TN / 2) + j * 32 + r, c);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int64_t n = n0 + wn * (TN / 2) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (m < a.M && n < a.N) {
+          float z;
+          if (LOO) {
+            const int64_t qi = a.row_begin + m;
+            const float x = a.Braw[n + qi * a.ldb];
+            const int has = ((x >= a.alpha) ? (a.weighted ? x : 1.0f) : 0.0f) != 0.0f ? 1 : 0;  // X[s][f_q]
+            const int d = a.ks[n] - has;
+            z = (d > 0 && n != qi) ? acc[i][j][q] * (1.0f / (float)d) : 0.0f;
+          } else {
+            z = acc[i][j][q] * a.inv_n[n];
+          }
+          a.out[m * a.ldo + n] = z;
+        }
+      }
+    }
+}
+
+template <bool LOO, int TN, int BK, int NST>
+static int launch_ring(DenseBf16Args& a, int64_t Mp, int64_t Np) {
+  constexpr size_t lds = (size_t)NST * (RING_TM + TN) * BK * 2;
+  static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
+  a.gx = (int)(Np / TN);
+  a.gy = (int)(Mp / RING_TM);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_dense_bf16_ring_kernel<LOO, TN, BK, NST>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((transfer_dense_bf16_ring_kernel<LOO, TN, BK, NST>), dim3((unsigned)(a.gx * a.gy)), dim3(512), lds,
+                     ctx().stream, a);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // planes of rows [row0, row0 + rows) of a column-major similarity block into `buf` (grown as needed)
 static int make_planes(const float* S, int64_t ld, int64_t row0, int64_t rows, int64_t K, float alpha, bool weighted,
                        const float* scale, int64_t loo_first, int np, DevBuf<unsigned short>& buf, int64_t* Rp_out,
                        int64_t* Kp_out) {
-  const int64_t Rp = round_up(rows > 0 ? rows : 1, BT), Kp = round_up(K > 0 ? K : 1, BKB);
+  const int64_t Rp = round_up(rows > 0 ? rows : 1, RING_TM), Kp = round_up(K > 0 ? K : 1, BKB);
   const size_t need = (size_t)np * Rp * Kp;
   if (buf.n < need) SS_TRY(buf.alloc(need));
   SS_HIP(hipMemsetAsync(buf.p, 0, need * sizeof(unsigned short), ctx().stream));
@@ -271,6 +420,13 @@ int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k,
   a.out = out;
   a.ldo = ldo;
   a.gx = (int)(Np / BT);
+  // enough 256 x 256 tiles to fill the chip: one workgroup per CU, two 64-KiB stages (measured at 50k, unweighted:
+  // 50 ms; 256 x 128 with three stages 58, 256 x 256 with K-steps of 32 and four / five stages 56 / 57, the
+  // 128 x 128 kernel with two workgroups per CU 65).  SS_DENSE_RING=0 / 1 forces the choice.
+  const bool ring_ok = (Mp / RING_TM) * (Np / 256) >= ctx().num_cu;
+  const char* ring_env = getenv("SS_DENSE_RING");  // 0: never, 1: always, unset: by size
+  if (ring_env ? atoi(ring_env) != 0 : ring_ok)
+    return loo ? launch_ring<true, 256, 64, 2>(a, Mp, Np) : launch_ring<false, 256, 64, 2>(a, Mp, Np);
   a.gy = (int)(Mp / BT);
   dim3 grid((unsigned)(a.gx * a.gy));
   if (loo) hipLaunchKernelGGL(transfer_dense_bf16_kernel<true>, grid, dim3(256), 0, ctx().stream, a);

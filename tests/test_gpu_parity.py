@@ -442,14 +442,17 @@ def test_config2_full_size_sampled_rows_and_linearity():
 
 
 # ----------------------------------------------------------------------------- dense-similarity regime (MFMA stage 1)
-@pytest.mark.parametrize("engine", ["bf16-planes", "fp32-mfma"])
+@pytest.mark.parametrize("engine", ["bf16-planes", "bf16-planes-ring", "fp32-mfma"])
 @pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("shape", [(70, 333, 41), (1, 64, 5), (130, 129, 300)])
 def test_dense_similarity_path_query_and_loo(shape, weighted, engine, monkeypatch):
     """Both stage-1 engines of the dense regime: the default bf16 MFMA on exact bf16 planes of the fp32 operands
-    (dense_bf16.hip: 3 plane products unweighted, 6 weighted) and the fp32-input MFMA kernel (SS_DENSE_BF16=0)."""
+    (dense_bf16.hip: 3 plane products unweighted, 6 weighted; 128 x 128 kernel and the 256 x 256 ring kernel) and the
+    fp32-input MFMA kernel (SS_DENSE_BF16=0)."""
     if engine == "fp32-mfma":
         monkeypatch.setenv("SS_DENSE_BF16", "0")
+    if engine == "bf16-planes-ring":     # the 256 x 256 ring kernel that large shapes pick by themselves
+        monkeypatch.setenv("SS_DENSE_RING", "1")
     nq, ns, nt = shape
     rng = np.random.default_rng(ns)
     Ss = rng.random((ns, ns)).astype(np.float32); Ss = ((Ss + Ss.T) / 2).astype(np.float32); np.fill_diagonal(Ss, 1.0)
