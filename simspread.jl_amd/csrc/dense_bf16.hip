@@ -82,6 +82,7 @@ struct DenseBf16Args {
   int64_t a_plane, b_plane;  // elements per plane
   int npairs;
   int pa[6], pb[6];
+  int bnew[6], bidx[6], nbs;  // ring kernel: source-tile staging plan of the pairs
   int64_t Kp, M, N;
   int64_t row_begin;         // LOO: query i = row_begin + m
   const float* inv_n;        // [N] 1/ks
@@ -205,10 +206,10 @@ __global__ void __launch_bounds__(256) transfer_dense_bf16_kernel(DenseBf16Args 
 // ------------------------------------------------------------------ the GEMM, three-stage ring
 // The kernel above requests a tile while the previous one is multiplied (512 cycles per wave), which is less than
 // the L2 latency, so it lives off the second workgroup of the CU.  Here one workgroup per CU (8 waves as 4 x 2,
-// 256 x TN tile, wave tile 64 x TN/2) keeps a ring of NST stages in LDS with NST - 1 K-steps in flight; with the
-// default 256 x 256 x 64 and two stages a K-step is 1024 MFMA cycles per wave, two waves per SIMD.  The LDS-DMA is
-// written as inline assembly so that the compiler does not drain it (s_waitcnt vmcnt(0)) in front of every ds_read;
-// completion is awaited with a counted s_waitcnt vmcnt(N) and one barrier per K-step.
+// 256 x TN tile, wave tile 64 x TN/2) keeps two-slot rings in LDS with the next step in flight; with the default
+// 256 x 256 x 64 a step is 1024 MFMA cycles per wave, two waves per SIMD.  The LDS-DMA is written as inline
+// assembly so that the compiler does not drain it (s_waitcnt vmcnt(0)) in front of every ds_read; completion is
+// awaited with an explicit s_waitcnt + one barrier per step.
 __device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base) : "memory");
 }
@@ -220,15 +221,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// TN: tile columns (128 or 256), BK: K per stage (32 or 64), NST: stages in the ring (NST - 1 in flight)
-template <bool LOO, int TN, int BK, int NST>
+// TN: tile columns (128 or 256), BK: K per step (32 or 64).  Steps run K-tile outer, plane pair inner, and the
+// operand tiles live in two separate two-slot rings: the query-side tile changes every step, the source-side tile
+// only when the pair names another source plane (unweighted: once per K-tile for the three query planes), so a
+// third of the DMA bytes go away -- and L2 -> LDS DMA at ~21 B/clk per CU is what a 256 x 256 x 64 step waits for.
+template <bool LOO, int TN, int BK>
 __global__ void __launch_bounds__(512) transfer_dense_bf16_ring_kernel(DenseBf16Args a) {
   constexpr int SLOTS = BK / 8, ROWB = BK * 2;          // 16-byte slots / bytes per tile row
-  constexpr int A_BYTES = RING_TM * ROWB, B_BYTES = TN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int NA = RING_TM * SLOTS / 512, NB = TN * SLOTS / 512, NDMA = NA + NB;  // DMA instructions per thread, stage
+  constexpr int A_BYTES = RING_TM * ROWB, B_BYTES = TN * ROWB;
+  constexpr int NA = RING_TM * SLOTS / 512, NB = TN * SLOTS / 512;  // DMA instructions per thread and tile
   constexpr int WN = TN / 64;                           // 32-column MFMA tiles per wave (wave tile 64 x TN/2)
-  static_assert((NST - 2) * NDMA <= 63, "vmcnt is a 6-bit counter");
-  extern __shared__ __align__(16) unsigned char ring[];
+  extern __shared__ __align__(16) unsigned char ring[];  // [A slot 0 | A slot 1 | B slot 0 | B slot 1]
   const unsigned ring0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves
@@ -251,27 +254,33 @@ __global__ void __launch_bounds__(512) transfer_dense_bf16_ring_kernel(DenseBf16
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int ksteps = (int)(a.Kp / BK);
-  const int total = a.npairs * ksteps;
+  const int np = a.npairs;
+  const int total = np * ksteps;
   auto swz = [](int row) __attribute__((always_inline)) { return SLOTS == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
-  auto stage = [&](int step) __attribute__((always_inline)) {
-    const int pair = step / ksteps, kt = step - pair * ksteps;
-    const unsigned short* Ap = a.A + (int64_t)a.pa[pair] * a.a_plane + m0 * a.Kp + (int64_t)kt * BK;
-    const unsigned short* Bp = a.B + (int64_t)a.pb[pair] * a.b_plane + n0 * a.Kp + (int64_t)kt * BK;
-    const unsigned base = ring0 + (unsigned)(step % NST) * STAGE_BYTES;
+  // step t = (K-tile kt, pair p).  a.bnew[p]: pair p stages a source tile; a.bidx[p]: which of the K-tile's
+  // source stagings pair p reads; a.nbs: source stagings per K-tile.  Source slot = (kt * nbs + bidx[p]) & 1.
+  auto stage = [&](int t) __attribute__((always_inline)) {
+    const int kt = t / np, p = t - kt * np;
+    const unsigned short* Ap = a.A + (int64_t)a.pa[p] * a.a_plane + m0 * a.Kp + (int64_t)kt * BK;
+    const unsigned abase = ring0 + (unsigned)(t & 1) * A_BYTES;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int p0 = wave * (64 * NA) + i * 64;
-      const int p = p0 + lane;
-      const int row = p / SLOTS, c = (p % SLOTS) ^ swz(row);
-      lds_dma16(Ap + (int64_t)row * a.Kp + 8 * c, __builtin_amdgcn_readfirstlane(base + (unsigned)p0 * 16u));
+      const int q = p0 + lane;
+      const int row = q / SLOTS, c = (q % SLOTS) ^ swz(row);
+      lds_dma16(Ap + (int64_t)row * a.Kp + 8 * c, __builtin_amdgcn_readfirstlane(abase + (unsigned)p0 * 16u));
     }
+    if (a.bnew[p]) {
+      const unsigned short* Bp = a.B + (int64_t)a.pb[p] * a.b_plane + n0 * a.Kp + (int64_t)kt * BK;
+      const unsigned bbase = ring0 + 2u * A_BYTES + (unsigned)((kt * a.nbs + a.bidx[p]) & 1) * B_BYTES;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int p0 = wave * (64 * NB) + i * 64;
-      const int p = p0 + lane;
-      const int row = p / SLOTS, c = (p % SLOTS) ^ swz(row);
-      lds_dma16(Bp + (int64_t)row * a.Kp + 8 * c, __builtin_amdgcn_readfirstlane(base + (unsigned)A_BYTES + (unsigned)p0 * 16u));
+      for (int i = 0; i < NB; ++i) {
+        const int p0 = wave * (64 * NB) + i * 64;
+        const int q = p0 + lane;
+        const int row = q / SLOTS, c = (q % SLOTS) ^ swz(row);
+        lds_dma16(Bp + (int64_t)row * a.Kp + 8 * c, __builtin_amdgcn_readfirstlane(bbase + (unsigned)p0 * 16u));
+      }
     }
   };
 
@@ -280,19 +289,14 @@ __global__ void __launch_bounds__(512) transfer_dense_bf16_ring_kernel(DenseBf16
     return *reinterpret_cast<const bf16x8*>(tile + row * ROWB + ((c ^ swz(row)) << 4));
   };
 
-#pragma unroll
-  for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < total) stage(s0);
-  for (int step = 0; step < total; ++step) {
-    // my pieces of stage `step` have landed when only the stages after it are still in flight
-    const int after = total - 1 - step;
-    if (after >= NST - 2) wait_vmcnt<(NST - 2) * NDMA>();
-    else if (NST > 3 && after == 1) wait_vmcnt<NDMA>();
-    else wait_vmcnt<0>();
-    __syncthreads();  // ... and everybody's; everybody is also done with stage step-1, whose slot is refilled now
-    if (step + NST - 1 < total) stage(step + NST - 1);
-    const unsigned char* At = ring + (step % NST) * STAGE_BYTES;
-    const unsigned char* Bt = At + A_BYTES;
+  stage(0);
+  for (int t = 0; t < total; ++t) {
+    wait_vmcnt<0>();   // my pieces of step t (requested one step ago) have landed ...
+    __syncthreads();   // ... and everybody's; everybody is also done with step t-1, whose slots are refilled now
+    if (t + 1 < total) stage(t + 1);
+    const int kt = t / np, p = t - kt * np;
+    const unsigned char* At = ring + (t & 1) * A_BYTES;
+    const unsigned char* Bt = ring + 2 * A_BYTES + ((kt * a.nbs + a.bidx[p]) & 1) * B_BYTES;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const int c = 2 * s + h;
@@ -333,19 +337,27 @@ __global__ void __launch_bounds__(512) transfer_dense_bf16_ring_kernel(DenseBf16
     }
 }
 
-template <bool LOO, int TN, int BK, int NST>
+template <bool LOO, int TN, int BK>
 static int launch_ring(DenseBf16Args& a, int64_t Mp, int64_t Np) {
-  constexpr size_t lds = (size_t)NST * (RING_TM + TN) * BK * 2;
-  static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
+  constexpr size_t lds = 2 * (size_t)(RING_TM + TN) * BK * 2;
+  static_assert(lds <= 160 * 1024, "rings do not fit the LDS");
   a.gx = (int)(Np / TN);
   a.gy = (int)(Mp / RING_TM);
+  // pair order of the ring kernel: pairs that read the same source plane next to one another
+  int nbs = 0;
+  for (int p = 0; p < a.npairs; ++p) {
+    a.bnew[p] = (p == 0 || a.pb[p] != a.pb[p - 1]) ? 1 : 0;
+    if (a.bnew[p]) ++nbs;
+    a.bidx[p] = nbs - 1;
+  }
+  a.nbs = nbs;
   static bool attr_set = false;
   if (!attr_set) {
-    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_dense_bf16_ring_kernel<LOO, TN, BK, NST>),
+    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_dense_bf16_ring_kernel<LOO, TN, BK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((transfer_dense_bf16_ring_kernel<LOO, TN, BK, NST>), dim3((unsigned)(a.gx * a.gy)), dim3(512), lds,
+  hipLaunchKernelGGL((transfer_dense_bf16_ring_kernel<LOO, TN, BK>), dim3((unsigned)(a.gx * a.gy)), dim3(512), lds,
                      ctx().stream, a);
   SS_LAUNCH_CHECK();
   return SS_OK;
@@ -398,10 +410,11 @@ int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k,
   a.a_plane = Mp * Kp;
   a.b_plane = Np * Kp;
   if (d.weighted) {
-    const int pa[6] = {0, 0, 1, 1, 0, 2}, pb[6] = {0, 1, 0, 1, 2, 0};
+    // the six largest plane products, grouped by source plane (so that the ring kernel stages a source tile once
+    // per group), smaller terms first inside a group
+    const int pa[6] = {0, 1, 0, 2, 1, 0}, pb[6] = {2, 1, 1, 0, 0, 0};
     a.npairs = 6;
-    // smallest products first: the fp32 accumulator then adds the large terms last
-    for (int i = 0; i < 6; ++i) { a.pa[i] = pa[5 - i]; a.pb[i] = pb[5 - i]; }
+    for (int i = 0; i < 6; ++i) { a.pa[i] = pa[i]; a.pb[i] = pb[i]; }
   } else {
     a.npairs = 3;
     a.pa[0] = 2; a.pa[1] = 1; a.pa[2] = 0;
@@ -420,13 +433,12 @@ int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k,
   a.out = out;
   a.ldo = ldo;
   a.gx = (int)(Np / BT);
-  // enough 256 x 256 tiles to fill the chip: one workgroup per CU, two 64-KiB stages (measured at 50k, unweighted:
-  // 50 ms; 256 x 128 with three stages 58, 256 x 256 with K-steps of 32 and four / five stages 56 / 57, the
+  // enough 256 x 256 tiles to fill the chip: one workgroup per CU (measured at 50k, unweighted: 44.6 ms; the
   // 128 x 128 kernel with two workgroups per CU 65).  SS_DENSE_RING=0 / 1 forces the choice.
   const bool ring_ok = (Mp / RING_TM) * (Np / 256) >= ctx().num_cu;
   const char* ring_env = getenv("SS_DENSE_RING");  // 0: never, 1: always, unset: by size
   if (ring_env ? atoi(ring_env) != 0 : ring_ok)
-    return loo ? launch_ring<true, 256, 64, 2>(a, Mp, Np) : launch_ring<false, 256, 64, 2>(a, Mp, Np);
+    return loo ? launch_ring<true, 256, 64>(a, Mp, Np) : launch_ring<false, 256, 64>(a, Mp, Np);
   a.gy = (int)(Mp / BT);
   dim3 grid((unsigned)(a.gx * a.gy));
   if (loo) hipLaunchKernelGGL(transfer_dense_bf16_kernel<true>, grid, dim3(256), 0, ctx().stream, a);
