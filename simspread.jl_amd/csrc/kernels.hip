@@ -911,7 +911,7 @@ static int launch_narrow_variant(const NarrowArgs<T>& a, unsigned grid, size_t l
 template <class T, int VEC>
 static int launch_narrow_lpn1(const NarrowArgs<T>& a, unsigned grid, size_t lds, double mean_quads) {
   constexpr int UR = VEC >= 8 ? 2 : 4;  // accumulators per lane = UR * VEC; stay inside 128 VGPRs
-  if (mean_quads > 40.0) return launch_narrow_variant<T, VEC, 1, 64, 2>(a, grid, lds);
+  if (mean_quads > 40.0) return launch_narrow_variant<T, VEC, 1, 64, (VEC <= 2 ? 4 : 2)>(a, grid, lds);
   if (mean_quads > 20.0) return launch_narrow_variant<T, VEC, 1, 32, UR>(a, grid, lds);
   if (mean_quads > 10.0) return launch_narrow_variant<T, VEC, 1, 16, UR>(a, grid, lds);
   return launch_narrow_variant<T, VEC, 1, 8, UR>(a, grid, lds);

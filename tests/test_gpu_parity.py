@@ -550,3 +550,30 @@ def test_recall_precision_at_L_reference_kat_and_device_scores(kats):
     hits = np.take_along_axis(Y, idx.cpu().numpy().astype(np.int64), 1).sum(1)
     grouping = np.repeat(np.arange(n), nt)
     assert ss.precisionatL(Y.ravel(), host.ravel(), grouping, 20) == pytest.approx(hits.mean() / 20)
+
+
+def test_timing_hold_accumulates_and_stream_ordered_predictions():
+    """ss_timing_hold: stage timings of successive calls add up; device row-major predictions are enqueued in
+    stream order (the second call may start before the host has seen the first finish) and still agree."""
+    import torch
+    rng = np.random.default_rng(9)
+    nq, ns, nt = 300, 400, 90
+    Xq = sp.random(nq, ns, density=0.1, format="csr", random_state=rng, dtype=np.float32)
+    Xs = sp.random(ns, ns, density=0.1, format="csr", random_state=rng, dtype=np.float32)
+    Ys = sp.random(ns, nt, density=0.05, format="csr", random_state=rng, dtype=np.float32); Ys.data[:] = 1.0
+    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    want = g.predict("query")                       # host result: complete on return
+    a = torch.empty((nq, nt), dtype=torch.float32, device="cuda")
+    b = torch.empty((nq, nt), dtype=torch.float32, device="cuda")
+    ss.timing_hold(True)
+    for _ in range(3):
+        g.predict("query", out=a)
+        g.predict("query", out=b)
+    t = ss.timing_last()
+    ss.timing_hold(False)
+    assert t["spmm_launches"] == 6 and t["transfer_launches"] == 6
+    assert t["spmm_ms"] > 0 and t["total_ms"] >= t["spmm_ms"] + t["transfer_ms"] - 1e-6
+    np.testing.assert_array_equal(a.cpu().numpy(), want)
+    np.testing.assert_array_equal(b.cpu().numpy(), want)
+    g.predict("query", out=a)
+    assert ss.timing_last()["spmm_launches"] == 1   # back to per-call timings
