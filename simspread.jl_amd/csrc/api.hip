@@ -362,6 +362,19 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
   const int64_t nj = g.ns;
   SS_TRY(graph_sell(g));
   if (!g.dense.on) SS_TRY(graph_chunked(g, kind == SS_ROWS_SOURCE));
+  if (g.dense.on && kind == SS_ROWS_SOURCE && g.YsTc.SC == 0) {
+    // the sparse target path needs Ys' cut into column chunks (same sizing rule as graph_chunked)
+    const int64_t ns = g.ns > 0 ? g.ns : 1;
+    const double mean_len = g.YsT.rows > 0 ? (double)g.YsT.nnz / (double)g.YsT.rows : 0.0;
+    int64_t sc = mean_len > 1.0 ? (int64_t)(64.0 * (double)ns / mean_len) : ns;
+    const int64_t sc_max = (20 * 1024) / (int64_t)sizeof(T) - 64;
+    if (sc > sc_max) sc = sc_max;
+    if (sc < 256) sc = 256;
+    int64_t nch = ceil_div(ns, sc);
+    if (nch > 1) nch = ceil_div(nch, 8) * 8;
+    sc = ceil_div(ceil_div(ns, nch), 4) * 4;
+    SS_TRY(chunked_build<T>(g.YsT, (int)sc, 1, g.YsTc));
+  }
   const int64_t rb = transfer_batch_rows(nrows, nj, sizeof(T));
   // the transfer block lives in the handle so that repeated predictions do not re-allocate
   const size_t need = (size_t)rb * (size_t)(nj > 0 ? nj : 1);
@@ -374,15 +387,23 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
       if (g.dense.on) {
         if constexpr (std::is_same<T, float>::value) {
           const bool loo = (kind == 2);
+          const bool srcrows = (kind == SS_ROWS_SOURCE);  // feature path here, target path added below
           // default: bf16 matrix cores on exact bf16 planes of the operands (dense_bf16.hip: 1.5x weighted, 3.2x
           // unweighted at 50k); SS_DENSE_BF16=0: the fp32-input MFMA kernel of dense.hip
           const bool use_bf16 = !(getenv("SS_DENSE_BF16") && atoi(getenv("SS_DENSE_BF16")) == 0);
           if (use_bf16)
             SS_TRY(launch_transfer_dense_bf16(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
-                                              row_begin + r0, nb, Tbuf.p, nj));
+                                              row_begin + r0, nb, Tbuf.p, nj, srcrows));
           else
             SS_TRY(launch_transfer_dense(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
-                                         row_begin + r0, nb, Tbuf.p, nj));
+                                         row_begin + r0, nb, Tbuf.p, nj, srcrows));
+          if (srcrows) {
+            // target path (Ys D_t^-1) Ys' D_s^-1 of the source rows: sparse, added to T
+            const DevCsr<T>* L[2] = {&g.Ys, nullptr};
+            const DevChunked<T>* M[2] = {&g.YsTc, nullptr};
+            const T* inv1[2] = {g.inv_kt.p, nullptr};
+            SS_TRY(launch_transfer<T>(1, L, inv1, M, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj, nullptr, true));
+          }
         } else {
           return fail(SS_EUNSUPPORTED, "the dense-similarity path is fp32 only");
         }
@@ -440,8 +461,6 @@ static int predict_impl(ss_graph* h, int kind, int64_t row_begin, int64_t row_en
   const int64_t limit = (kind == SS_ROWS_QUERY) ? g.nq : g.ns;
   if (g.general && kind != SS_ROWS_QUERY)
     return fail(SS_EINVAL, "a general graph serves SS_ROWS_QUERY only");
-  if (g.dense.on && kind == SS_ROWS_SOURCE)
-    return fail(SS_EUNSUPPORTED, "source rows are not served by the dense-similarity path yet");
   if (kind == 2) {
     if ((!g.dense.on && g.nq != 0) || g.ns != g.nf)
       return fail(SS_EINVAL, "leave-one-out needs a graph with nq == 0 and ns == nf (feature j named after source j)");

@@ -387,7 +387,7 @@ static int make_planes(const float* S, int64_t ld, int64_t row0, int64_t rows, i
 }
 
 int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
-                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo) {
+                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows) {
   if (nrows <= 0 || d.ns <= 0) return SS_OK;
   // source side: once per graph (alpha and the weighting are fixed in the handle)
   const int npb = d.weighted ? 3 : 1;
@@ -402,8 +402,9 @@ int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k,
   Kp = d.Bpl_Kp;
   // query side: this block of rows, threshold * 1/kf (LOO: 1/(kf-1), own feature dropped)
   int64_t Mp = 0, Kp2 = 0;
-  SS_TRY(make_planes(loo ? d.Ss.p : d.Sq.p, loo ? d.ns : d.nq, row_begin, nrows, d.nf, d.alpha, d.weighted, inv_k,
-                     loo ? row_begin : -1, 3, d.Apl, &Mp, &Kp2));
+  const bool from_ss = loo || source_rows;  // rows of the source similarity itself (LOO: own feature dropped)
+  SS_TRY(make_planes(from_ss ? d.Ss.p : d.Sq.p, from_ss ? d.ns : d.nq, row_begin, nrows, d.nf, d.alpha, d.weighted,
+                     inv_k, loo ? row_begin : -1, 3, d.Apl, &Mp, &Kp2));
   DenseBf16Args a{};
   a.A = d.Apl.p;
   a.B = d.Bpl.p;

@@ -158,7 +158,7 @@ int launch_spread_dense(const T* G, int64_t rows, int64_t cols, int64_t ld, cons
 template <class T>
 int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
                     const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld,
-                    const int* row_ids = nullptr);
+                    const int* row_ids = nullptr, bool accumulate = false);
 // k-fold: degrees / reciprocal degrees of the graph without the members of one fold
 template <class T>
 int launch_fold_degrees(const DevCsr<T>& X, const DevCsr<T>& XT, const DevCsr<T>& Y, const int* members,
@@ -204,11 +204,11 @@ int launch_rank_metrics(const unsigned char* y, const float* yhat, int64_t n, do
 
 // ---- dense.hip (fp32 only: fp32-input MFMA)
 int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
-                          int64_t row_begin, int64_t nrows, float* out, int64_t ldo);
+                          int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows = false);
 int dense_degrees(Graph<float>& g);
 // dense_bf16.hip: the same product on the bf16 matrix cores with the operands split into exact bf16 planes
 int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
-                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo);
+                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows = false);
 
 template <class T>
 int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout);

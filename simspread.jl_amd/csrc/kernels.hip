@@ -124,6 +124,7 @@ struct TransferArgs {
   int nchunks;
   T* out;
   int64_t ld;
+  int accumulate;  // add to what `out` already holds (dense regime: the feature path came from the GEMM)
 };
 
 // One single-wave workgroup per (row r of L, column chunk c of T); c = blockIdx % nchunks so that,
@@ -296,6 +297,7 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
       z = (d > 0 && (j0 + j) != gr) ? acc[j] * (T(1) / T(d)) : T(0);
     } else {
       z = acc[j] * p.inv2[j0 + j];
+      if (p.accumulate) z += orow[j];
     }
     orow[j] = z;
   }
@@ -306,7 +308,7 @@ constexpr int TRANSFER_U = 8;
 template <class T>
 int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
                     const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld,
-                    const int* row_ids) {
+                    const int* row_ids, bool accumulate) {
   if (nrows <= 0 || nj <= 0) return SS_OK;
   TransferArgs<T> p{};
   p.nterms = nterms;
@@ -325,6 +327,7 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
   p.nchunks = Mt[0]->nchunks;
   p.out = out;
   p.ld = ld;
+  p.accumulate = accumulate ? 1 : 0;
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
   const size_t lds = (size_t)(p.SC + 64) * sizeof(T);
@@ -1322,7 +1325,7 @@ int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, i
   template int launch_row_degree<T>(const T*, int64_t, int64_t, int64_t, int*);                             \
   template int launch_spread_dense<T>(const T*, int64_t, int64_t, int64_t, const int*, T*, int64_t);        \
   template int launch_transfer<T>(int, const DevCsr<T>*[2], const T*[2], const DevChunked<T>*[2], const T*, \
-                                  int64_t, int64_t, int64_t, T*, int64_t, const int*);                      \
+                                  int64_t, int64_t, int64_t, T*, int64_t, const int*, bool);                      \
   template int launch_fold_degrees<T>(const DevCsr<T>&, const DevCsr<T>&, const DevCsr<T>&, const int*,     \
                                       int64_t, int*, int*, int*);                                           \
   template int launch_fold_inverse<T>(const int*, const int*, const int*, int, int64_t, int64_t, T*, T*);   \

@@ -472,8 +472,10 @@ def test_dense_similarity_path_query_and_loo(shape, weighted, engine, monkeypatc
     assert_close(g.predict_loo(clean=True), want, np.float32)
     lo, hi = ns // 3, ns - 1
     assert_close(g.predict_loo(lo, hi, clean=True, layout="col"), want[lo:hi], np.float32)
-    with pytest.raises(ss.SimSpreadError):
-        g.predict("source")
+    # source rows (= predict(A, ytrain), src/core.jl:446-466): feature path on the matrix cores + sparse target path
+    gs = ss.DeviceGraph.from_dense(None, Ss, Y.toarray(), alpha=alpha, weighted=weighted, dtype=np.float64)
+    assert_close(g.predict("source"), gs.predict("source"), np.float32)
+    assert_close(g.predict("source", lo, hi, clean=True), gs.predict("source", lo, hi, clean=True), np.float32)
 
 
 def test_dense_similarity_equals_sparse_path_on_the_same_input():
