@@ -323,7 +323,7 @@ def test_loo_through_the_mirror_equals_fold_loop():
 
 # ----------------------------------------------------------------------------- raw W*R SpMM
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("B", [1, 2, 3, 4, 7, 16, 33, 64, 65, 200])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 7, 8, 12, 16, 32, 33, 64, 65, 200])
 def test_spmm_against_scipy(B, dtype):
     rng = np.random.default_rng(B)
     M, K = 517, 389
@@ -364,10 +364,10 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
     monkeypatch.setenv("SS_NARROW_CHUNK", "700")
     w = ss.DeviceSpMat(W, dtype=np.float64)
     assert_close(w.spmm(R), W @ R, np.float64)
-    for B in (1, 2, 5, 16):       # LDS-chunked narrow kernel, 8 chunks, partial sums combined in order
+    for B in (1, 2, 5, 8, 16):    # narrow kernel (B <= 8: 8 chunks, partial sums combined in order) / row-block kernel
         assert_close(w.spmm(R[:, :B].copy()), W @ R[:, :B], np.float64)
     w32 = ss.DeviceSpMat(W, dtype=np.float32)
-    for B in (1, 4, 9, 17, 40, 64):   # 17..64: register-accumulator kernel, 8 LDS chunks of R
+    for B in (1, 4, 8, 9, 17, 32, 40, 64):   # 8..32: row-block kernel over 8 LDS chunks of R; wider: SELL kernel
         assert_close(w32.spmm(R[:, :B].astype(np.float32)), W @ R[:, :B], np.float32)
     monkeypatch.setenv("SS_NARROW_CSR", "1")   # the L2-gather CSR kernel (what 16 < B <= 64 uses)
     assert_close(w.spmm(R[:, :5].copy()), W @ R[:, :5], np.float64)
