@@ -83,6 +83,14 @@ int ss_timing_last(double* ms, int n);
  * every call to read them; enable == 0: back to per-call timings. */
 int ss_timing_hold(int enable);
 
+/* ------------------------------------------------------ similarity producer -- */
+/* The step before featurize in the reference's tutorial (docs/src/tutorial/fishers-flowers.jl:66,
+ * `1 .- pairwise(Jaccard(), X, dims=1)`): S[i][j] = sum_k min(F[i,k],F[j,k]) / sum_k max(F[i,k],F[j,k]) between the
+ * rows of the n x d feature matrix F (column-major, ld >= n); S is n x n column-major (lds >= n), symmetric with
+ * unit diagonal; two all-zero rows have similarity 1 (Distances.jl: distance 0). */
+int ss_similarity_jaccard_f32(const float* F, int64_t n, int64_t d, int64_t ld, float* S, int64_t lds, int mem);
+int ss_similarity_jaccard_f64(const double* F, int64_t n, int64_t d, int64_t ld, double* S, int64_t lds, int mem);
+
 /* ------------------------------------------------------- cutoff / k / spread -- */
 /* cutoff(X, alpha, weighted): out = x >= alpha ? (weighted ? x : 1) : 0, element-wise
  * (src/core.jl:37-43,55-60; `>=` inclusive per test/runtests.jl:46-47).  Also the value

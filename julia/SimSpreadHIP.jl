@@ -203,4 +203,17 @@ function rank_metrics(y::AbstractVector, yhat::AbstractVector; alpha::Float64=20
     return (AuROC=out[1], AuPRC=out[2], BEDROC=out[3], validity_ratio=out[4])
 end
 
+"""
+    jaccard_similarity(X) -> Matrix
+
+`1 .- pairwise(Jaccard(), X, dims=1)` (the similarity producer of the tutorial) on the device.
+"""
+function jaccard_similarity(X::Matrix{Float64})
+    n, d = size(X)
+    S = Matrix{Float64}(undef, n, n)
+    check(ccall((:ss_similarity_jaccard_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
+                X, n, d, max(n, 1), S, max(n, 1), SS_MEM_HOST))
+    return S
+end
+
 end # module

@@ -59,6 +59,7 @@ def _sigs():
     s["ss_graph_create_similarity_f32"] = ([_i64] * 3 + [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _int, f32, _int, _int, _vp], _int)
     for suf, ft in (("f32", f32), ("f64", f64)):
         s[f"ss_cutoff_{suf}"] = ([_vp, _i64, _i64, _i64, ft, _int, _vp, _i64, _int], _int)
+        s[f"ss_similarity_jaccard_{suf}"] = ([_vp, _i64, _i64, _i64, _vp, _i64, _int], _int)
         s[f"ss_row_degree_{suf}"] = ([_vp, _i64, _i64, _i64, _vp, _int], _int)
         s[f"ss_spread_{suf}"] = ([_vp, _i64, _i64, _i64, _vp, _i64, _int], _int)
         s[f"ss_graph_create_csr_{suf}"] = ([_i64] * 4 + [_vp] * 9 + [_int, _int, _vp], _int)

@@ -862,6 +862,26 @@ static std::recursive_mutex& api_mutex() {
 }
 #define SS_API_LOCK() std::lock_guard<std::recursive_mutex> _ss_api_guard(api_mutex())
 
+template <class T>
+static int jaccard_impl(const T* F, int64_t n, int64_t d, int64_t ld, T* S, int64_t lds_, int mem) {
+  SS_TRY(require_init());
+  SS_TRY(check_mem(mem));
+  if (n < 0 || d < 0 || ld < n || lds_ < n) return fail(SS_EINVAL, "similarity: bad shape / leading dimension");
+  if (n == 0) return SS_OK;
+  if ((d > 0 && !F) || !S) return fail(SS_EINVAL, "similarity: NULL buffer");
+  hipStream_t st = ctx().stream;
+  if (mem == SS_MEM_DEVICE) return launch_jaccard<T>(F, n, d, ld, S, lds_);
+  DevBuf<T> dF, dS;
+  SS_TRY(dF.alloc((size_t)n * (d > 0 ? d : 1)));
+  SS_TRY(dS.alloc((size_t)n * n));
+  if (d > 0)
+    SS_HIP(hipMemcpy2DAsync(dF.p, n * sizeof(T), F, ld * sizeof(T), n * sizeof(T), d, hipMemcpyHostToDevice, st));
+  SS_TRY(launch_jaccard<T>(dF.p, n, d, n, dS.p, n));
+  SS_HIP(hipMemcpy2DAsync(S, lds_ * sizeof(T), dS.p, n * sizeof(T), n * sizeof(T), n, hipMemcpyDeviceToHost, st));
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
 extern "C" {
 
 int ss_version(void) { return SS_VERSION; }
@@ -969,6 +989,15 @@ int ss_timing_last(double* ms, int n) {
   }
   for (int i = 0; i < n && i < 8; ++i) ms[i] = t.resolved[i];
   return SS_OK;
+}
+
+int ss_similarity_jaccard_f32(const float* F, int64_t n, int64_t d, int64_t ld, float* S, int64_t lds_, int mem) {
+  SS_API_LOCK();
+  return jaccard_impl<float>(F, n, d, ld, S, lds_, mem);
+}
+int ss_similarity_jaccard_f64(const double* F, int64_t n, int64_t d, int64_t ld, double* S, int64_t lds_, int mem) {
+  SS_API_LOCK();
+  return jaccard_impl<double>(F, n, d, ld, S, lds_, mem);
 }
 
 int ss_cutoff_f32(const float* X, int64_t rows, int64_t cols, int64_t ld, float alpha, int weighted, float* out,

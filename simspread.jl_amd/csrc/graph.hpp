@@ -198,6 +198,10 @@ int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, fl
 template <class T>
 int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
 
+// similarity producer of the reference's tutorial: weighted Jaccard between the rows of a feature matrix
+template <class T>
+int launch_jaccard(const T* F, int64_t n, int64_t d, int64_t ld, T* S, int64_t lds);
+
 int launch_topl(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L, int* oidx, float* oval);
 // metrics.hip: AuROC, AuPRC, BEDROC(alpha), validity ratio of one score vector (device inputs, host outputs)
 int launch_rank_metrics(const unsigned char* y, const float* yhat, int64_t n, double alpha, double* out4);

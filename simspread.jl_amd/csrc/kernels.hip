@@ -1320,8 +1320,76 @@ int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, i
 }
 
 // ============================================================== explicit instantiations
+// ============================================================== similarity producer (the step before featurize)
+// S[i][j] = sum_k min(F[i,k], F[j,k]) / sum_k max(F[i,k], F[j,k]): the weighted Jaccard (Ruzicka) similarity of
+// the reference's tutorial, `1 .- pairwise(Jaccard(), X, dims=1)` (docs/src/tutorial/fishers-flowers.jl:66;
+// Distances.jl: distance 0 when both rows are all zero).  F: n x d column-major; S: n x n column-major.
+// 64 x 64 tile per workgroup, 4 x 4 pairs per thread, feature columns staged 16 at a time through LDS; only the
+// tiles on and above the diagonal are computed, the mirror image is written with them.
+template <class T>
+__global__ void __launch_bounds__(256) jaccard_kernel(const T* __restrict__ F, int64_t n, int64_t d, int64_t ld,
+                                                      T* __restrict__ S, int64_t lds_) {
+  constexpr int TS = 64, BK = 16;
+  if (blockIdx.y < blockIdx.x) return;  // lower triangle comes from the mirror write
+  __shared__ T A[BK][TS + 1];
+  __shared__ T B[BK][TS + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t i0 = (int64_t)blockIdx.x * TS, j0 = (int64_t)blockIdx.y * TS;
+  T smin[4][4], smax[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { smin[a][b] = T(0); smax[a][b] = T(0); }
+  for (int64_t k0 = 0; k0 < d; k0 += BK) {
+    for (int e = tid; e < BK * TS; e += 256) {
+      const int kk = e / TS, r = e % TS;
+      const int64_t k = k0 + kk;
+      A[kk][r] = (k < d && i0 + r < n) ? F[i0 + r + k * ld] : T(0);
+      B[kk][r] = (k < d && j0 + r < n) ? F[j0 + r + k * ld] : T(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      T av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = A[kk][tx + 16 * a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = B[kk][ty + 16 * b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          smin[a][b] += av[a] < bv[b] ? av[a] : bv[b];
+          smax[a][b] += av[a] < bv[b] ? bv[b] : av[a];
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int64_t i = i0 + tx + 16 * a, j = j0 + ty + 16 * b;
+      if (i < n && j < n) {
+        const T v = smax[a][b] == T(0) ? T(1) : smin[a][b] / smax[a][b];
+        S[i + j * lds_] = v;
+        S[j + i * lds_] = v;
+      }
+    }
+}
+
+template <class T>
+int launch_jaccard(const T* F, int64_t n, int64_t d, int64_t ld, T* S, int64_t lds_) {
+  if (n <= 0) return SS_OK;
+  const unsigned g = (unsigned)ceil_div(n, 64);
+  hipLaunchKernelGGL(jaccard_kernel<T>, dim3(g, g), dim3(256), 0, ctx().stream, F, n, d, ld, S, lds_);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
 #define SS_INSTANTIATE(T)                                                                                   \
   template int launch_cutoff<T>(const T*, int64_t, int64_t, int64_t, T, bool, T*, int64_t);                 \
+  template int launch_jaccard<T>(const T*, int64_t, int64_t, int64_t, T*, int64_t);                        \
   template int launch_row_degree<T>(const T*, int64_t, int64_t, int64_t, int*);                             \
   template int launch_spread_dense<T>(const T*, int64_t, int64_t, int64_t, const int*, T*, int64_t);        \
   template int launch_transfer<T>(int, const DevCsr<T>*[2], const T*[2], const DevChunked<T>*[2], const T*, \

@@ -403,3 +403,27 @@ def rank_metrics(y, yhat, alpha: float = 20.0) -> dict:
             raise AssertionError("The number of scores must be equal to the number of labels")
         L_.check(lib.ss_rank_metrics_f32(yl.ctypes.data, sc.ctypes.data, sc.size, float(alpha), out, L_.SS_MEM_HOST))
     return {"AuROC": out[0], "AuPRC": out[1], "BEDROC": out[2], "validity_ratio": out[3]}
+
+
+def jaccard_similarity(X, dtype=np.float64):
+    """Weighted Jaccard (Ruzicka) similarity between the rows of a feature matrix, on the device: the similarity
+    producer of the reference's tutorial (`1 .- pairwise(Jaccard(), X, dims=1)`, docs/src/tutorial/fishers-flowers.jl:66).
+    X: (n, d) numpy array or torch CUDA tensor; returns (n, n) of the same kind."""
+    lib = L_.lib()
+    if _is_torch(X):
+        import torch
+        if X.dtype not in (torch.float32, torch.float64):
+            raise TypeError("X must be float32 or float64")
+        suf = "f32" if X.dtype == torch.float32 else "f64"
+        n, d = X.shape
+        Xc = X.t().contiguous()                    # column-major n x d
+        S = torch.empty((n, n), dtype=X.dtype, device=X.device)
+        L_.check(getattr(lib, f"ss_similarity_jaccard_{suf}")(Xc.data_ptr(), n, d, n, S.data_ptr(), n, L_.SS_MEM_DEVICE))
+        return S                                   # symmetric: row- and column-major coincide
+    dt = np.dtype(dtype)
+    suf = "f32" if dt == np.float32 else "f64"
+    Xf = np.asfortranarray(np.asarray(X, dtype=dt))
+    n, d = Xf.shape
+    S = np.empty((n, n), dtype=dt, order="F")
+    L_.check(getattr(lib, f"ss_similarity_jaccard_{suf}")(Xf.ctypes.data, n, d, max(n, 1), S.ctypes.data, max(n, 1), L_.SS_MEM_HOST))
+    return np.ascontiguousarray(S)

@@ -579,3 +579,34 @@ def test_timing_hold_accumulates_and_stream_ordered_predictions():
     np.testing.assert_array_equal(b.cpu().numpy(), want)
     g.predict("query", out=a)
     assert ss.timing_last()["spmm_launches"] == 1   # back to per-call timings
+
+
+# ----------------------------------------------------------------------------- similarity producer (tutorial step)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_jaccard_similarity_reproduces_the_reference_iris_simmat(dtype):
+    """docs/src/tutorial/fishers-flowers.jl:66 on docs/src/tutorial/data/iris.features must give iris.simmat
+    (both files are committed fixtures of the reference: tests/golden/iris)."""
+    here = os.path.join(os.path.dirname(__file__), "golden", "iris")
+    def read(p):
+        with open(os.path.join(here, p)) as f:
+            lines = f.read().splitlines()
+        return np.array([[float(v) for v in l.split()[1:]] for l in lines[1:]])
+    F, want = read("iris.features"), read("iris.simmat")
+    got = ss.jaccard_similarity(F, dtype=dtype)
+    assert got.shape == (150, 150) and got.dtype == dtype
+    np.testing.assert_allclose(got, want, rtol=1e-12 if dtype == np.float64 else 2e-6, atol=0)
+    np.testing.assert_array_equal(got, got.T)
+    np.testing.assert_array_equal(np.diag(got), np.ones(150, dtype))
+
+
+def test_jaccard_similarity_shapes_and_zero_rows():
+    import torch
+    rng = np.random.default_rng(4)
+    X = rng.random((203, 37))
+    X[5] = 0; X[77] = 0                      # all-zero rows: similarity 1 to each other, 0 to the rest
+    mn = np.minimum(X[:, None, :], X[None, :, :]).sum(-1); mx = np.maximum(X[:, None, :], X[None, :, :]).sum(-1)
+    want = np.where(mx == 0, 1.0, mn / np.where(mx == 0, 1, mx))
+    np.testing.assert_allclose(ss.jaccard_similarity(X), want, rtol=1e-12)
+    got = ss.jaccard_similarity(torch.from_numpy(X.astype(np.float32)).cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=3e-6)
+    assert ss.jaccard_similarity(np.zeros((0, 4))).shape == (0, 0)

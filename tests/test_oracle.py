@@ -168,10 +168,8 @@ def _iris():
     return rows, cc, mn / mx, C
 
 
-def test_iris_simmat_matches_reference_file_when_present():
-    p = "/root/reference/docs/src/tutorial/data/iris.simmat"
-    if not os.path.exists(p):
-        pytest.skip("reference tree not present (GPU box)")
+def test_iris_simmat_matches_reference_file():
+    p = os.path.join(os.path.dirname(__file__), "golden", "iris", "iris.simmat")
     rows, _, S, _ = _iris()
     with open(p) as f:
         lines = f.read().splitlines()
