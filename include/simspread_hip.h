@@ -140,7 +140,8 @@ int ss_graph_create_dense_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt,
  * the stage-1 product, which runs on the matrix cores (bf16 MFMA over exact bf16 planes of the fp32 operands;
  * SS_DENSE_BF16=0: fp32-input MFMA); the labels Y stay sparse (CSR, ns x nt).
  * Sq (nq x ns) and Ss (ns x ns) are column-major raw similarities whose columns are the features named
- * after the sources; nq may be 0.  Serves ss_predict_f32 (query and source rows) and ss_predict_loo_f32.
+ * after the sources; nq may be 0.  Serves ss_predict_f32 (query and source rows), ss_predict_loo_f32 and
+ * ss_predict_kfold_f32.
  * fp32 only (the exact-fp32 matrix instruction); there is no _f64 form. */
 int ss_graph_create_similarity_f32(int64_t nq, int64_t ns, int64_t nt,
                                    const float* Sq, int64_t ldq, const float* Ss, int64_t lds,

@@ -535,8 +535,8 @@ static int predict_kfold_impl(ss_graph* h, const int32_t* fold_of_source, int nf
   Graph<T>* gp = nullptr;
   SS_TRY(graph_check<T>(h, &gp));
   Graph<T>& g = *gp;
-  if (g.general || g.dense.on || g.nq != 0 || g.ns != g.nf)
-    return fail(SS_EINVAL, "k-fold needs a sparse graph with nq == 0 and ns == nf (feature j named after source j)");
+  if (g.general || (!g.dense.on && g.nq != 0) || g.ns != g.nf)
+    return fail(SS_EINVAL, "k-fold needs a graph with nq == 0 and ns == nf (feature j named after source j)");
   if (nfolds < 1 || !fold_of_source) return fail(SS_EINVAL, "k-fold: bad fold assignment");
   const int64_t ns = g.ns, nt = g.nt;
   if (ns == 0 || nt == 0) return SS_OK;
@@ -566,7 +566,7 @@ static int predict_kfold_impl(ss_graph* h, const int32_t* fold_of_source, int nf
   SS_HIP(hipMemcpyAsync(d_fold.p, fold.data(), ns * sizeof(int), hipMemcpyHostToDevice, st));
   SS_HIP(hipMemcpyAsync(d_order.p, order.data(), ns * sizeof(int), hipMemcpyHostToDevice, st));
   SS_TRY(graph_sell(g));
-  SS_TRY(graph_chunked(g, false));
+  if (!g.dense.on) SS_TRY(graph_chunked(g, false));
 
   timing_begin_call();
   hipEvent_t e_begin, e_end;
@@ -588,7 +588,12 @@ static int predict_kfold_impl(ss_graph* h, const int32_t* fold_of_source, int nf
     SS_HIP(hipMemcpyAsync(kf.p, g.kf.p, g.nf * sizeof(int), hipMemcpyDeviceToDevice, st));
     SS_HIP(hipMemcpyAsync(ks.p, g.ks.p, ns * sizeof(int), hipMemcpyDeviceToDevice, st));
     SS_HIP(hipMemcpyAsync(kt.p, g.kt.p, nt * sizeof(int), hipMemcpyDeviceToDevice, st));
-    SS_TRY(launch_fold_degrees<T>(g.Xs, g.XsT, g.Ys, members, nm, kf.p, ks.p, kt.p));
+    if (g.dense.on) {
+      if constexpr (std::is_same<T, float>::value) SS_TRY(dense_fold_degrees(g, members, nm, kf.p, ks.p, kt.p));
+      else return fail(SS_EUNSUPPORTED, "the dense-similarity path is fp32 only");
+    } else {
+      SS_TRY(launch_fold_degrees<T>(g.Xs, g.XsT, g.Ys, members, nm, kf.p, ks.p, kt.p));
+    }
     SS_TRY(launch_fold_inverse<T>(kf.p, ks.p, d_fold.p, phi, g.nf, ns, inv_kf.p, inv_ks.p));
     const int64_t rb = transfer_batch_rows(nm, ns, sizeof(T));
     const size_t need = (size_t)rb * (size_t)ns;
@@ -597,10 +602,18 @@ static int predict_kfold_impl(ss_graph* h, const int32_t* fold_of_source, int nf
       const int64_t nb = (nm - r0 < rb) ? (nm - r0) : rb;
       {
         StageTimer t1(ST_TRANSFER);
-        const DevCsr<T>* L[2] = {&g.Xs, nullptr};
-        const DevChunked<T>* M[2] = {&g.XsTc, nullptr};
-        const T* inv1[2] = {inv_kf.p, nullptr};
-        SS_TRY(launch_transfer<T>(1, L, inv1, M, inv_ks.p, r0, nb, ns, g.Tws.p, ns, members));
+        if (g.dense.on) {
+          // members' rows gathered into the query planes with this fold's 1/kf (0 on the members' own feature
+          // columns); the epilogue multiplies by this fold's 1/ks (0 for the members as sources)
+          if constexpr (std::is_same<T, float>::value)
+            SS_TRY(launch_transfer_dense_bf16(g.dense, false, inv_kf.p, inv_ks.p, nullptr, r0, nb, g.Tws.p, ns, false,
+                                              members));
+        } else {
+          const DevCsr<T>* L[2] = {&g.Xs, nullptr};
+          const DevChunked<T>* M[2] = {&g.XsTc, nullptr};
+          const T* inv1[2] = {inv_kf.p, nullptr};
+          SS_TRY(launch_transfer<T>(1, L, inv1, M, inv_ks.p, r0, nb, ns, g.Tws.p, ns, members));
+        }
         timing_count(ST_NTRANSFER, 1);
       }
       if (!g.W.sorted) {

@@ -275,6 +275,58 @@ int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k
   return SS_OK;
 }
 
+// ------------------------------------------------------------------ k-fold: degrees of the graph without one fold
+// kf[f] -= #{members m : cut(S[m,f]) != 0} (one wave per feature column, lanes walk the members),
+// ks[s] -= #{member features m : cut(S[s,m]) != 0} (thread per source row, coalesced along the column),
+// kt[t] -= #{members m : Y[m,t] != 0} (CSR rows of the members).
+__global__ void dense_fold_kf_kernel(const float* __restrict__ S, int64_t ld, int64_t nf, float alpha, int weighted,
+                                     const int* __restrict__ members, int64_t nm, int* __restrict__ kf) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t f = wave0; f < nf; f += nwaves) {
+    int n = 0;
+    for (int64_t i = lane; i < nm; i += 64) n += cut_val(S[members[i] + f * ld], alpha, weighted) != 0.0f ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if (lane == 0) kf[f] -= n;
+  }
+}
+__global__ void dense_fold_ks_kernel(const float* __restrict__ S, int64_t ld, int64_t ns, float alpha, int weighted,
+                                     const int* __restrict__ members, int64_t nm, int* __restrict__ ks) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += (int64_t)gridDim.x * blockDim.x) {
+    int n = 0;
+    for (int64_t i = 0; i < nm; ++i) n += cut_val(S[s + (int64_t)members[i] * ld], alpha, weighted) != 0.0f ? 1 : 0;
+    ks[s] -= n;
+  }
+}
+__global__ void dense_fold_kt_kernel(const int* __restrict__ yptr, const int* __restrict__ yidx,
+                                     const int* __restrict__ members, int64_t nm, int* __restrict__ kt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t m = wave0; m < nm; m += nwaves) {
+    const int g = members[m];
+    for (int x = yptr[g] + lane; x < yptr[g + 1]; x += 64) atomicSub(&kt[yidx[x]], 1);
+  }
+}
+
+int dense_fold_degrees(const Graph<float>& g, const int* members, int64_t nm, int* kf, int* ks, int* kt) {
+  if (nm <= 0) return SS_OK;
+  const DenseSim<float>& d = g.dense;
+  hipStream_t st = ctx().stream;
+  const auto cap = [](int64_t x) { return (unsigned)(x < 1 ? 1 : (x > 4096 ? 4096 : x)); };
+  hipLaunchKernelGGL(dense_fold_kf_kernel, dim3(cap(ceil_div(d.nf * 64, 256))), dim3(256), 0, st, d.Ss.p, d.ns, d.nf,
+                     d.alpha, d.weighted ? 1 : 0, members, nm, kf);
+  SS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dense_fold_ks_kernel, dim3(cap(ceil_div(d.ns, 256))), dim3(256), 0, st, d.Ss.p, d.ns, d.ns, d.alpha,
+                     d.weighted ? 1 : 0, members, nm, ks);
+  SS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dense_fold_kt_kernel, dim3(cap(ceil_div(nm * 64, 256))), dim3(256), 0, st, g.Ys.ptr.p, g.Ys.idx.p,
+                     members, nm, kt);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
 // degrees of the thresholded similarity + labels: kf (columns of cut(Ss)), ks (rows of cut(Ss) + rows of Y)
 int dense_degrees(Graph<float>& g) {
   hipStream_t st = ctx().stream;

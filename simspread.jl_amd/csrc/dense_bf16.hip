@@ -41,6 +41,7 @@ template <int NP>
 __global__ void __launch_bounds__(256) dense_planes_kernel(const float* __restrict__ S, int64_t ld, int64_t row0,
                                                             int64_t rows, int64_t K, float alpha, int weighted,
                                                             const float* __restrict__ scale, int64_t loo_first,
+                                                            const int* __restrict__ row_ids,
                                                             unsigned short* __restrict__ dst, int64_t Rp, int64_t Kp) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(256) dense_planes_kernel(const float* __restri
     const int64_t k = k0 + ty + 8 * i, r = r0 + tx;
     float v = 0.f;
     if (k < K && r < rows) {
-      const float x = S[row0 + r + k * ld];
+      const float x = S[(row_ids ? (int64_t)row_ids[row0 + r] : row0 + r) + k * ld];  // k-fold: rows of a fold's members
       v = (x >= alpha) ? (weighted ? x : 1.0f) : 0.0f;
       if (scale) v *= scale[k];
       if (loo_first >= 0 && k == loo_first + r) v = 0.f;
@@ -367,8 +368,8 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 
 // planes of rows [row0, row0 + rows) of a column-major similarity block into `buf` (grown as needed)
 static int make_planes(const float* S, int64_t ld, int64_t row0, int64_t rows, int64_t K, float alpha, bool weighted,
-                       const float* scale, int64_t loo_first, int np, DevBuf<unsigned short>& buf, int64_t* Rp_out,
-                       int64_t* Kp_out) {
+                       const float* scale, int64_t loo_first, const int* row_ids, int np, DevBuf<unsigned short>& buf,
+                       int64_t* Rp_out, int64_t* Kp_out) {
   const int64_t Rp = round_up(rows > 0 ? rows : 1, RING_TM), Kp = round_up(K > 0 ? K : 1, BKB);
   const size_t need = (size_t)np * Rp * Kp;
   if (buf.n < need) SS_TRY(buf.alloc(need));
@@ -376,10 +377,10 @@ static int make_planes(const float* S, int64_t ld, int64_t row0, int64_t rows, i
   dim3 grid((unsigned)ceil_div(rows, 32), (unsigned)ceil_div(K, 32));
   if (np == 1)
     hipLaunchKernelGGL(dense_planes_kernel<1>, grid, dim3(256), 0, ctx().stream, S, ld, row0, rows, K, alpha,
-                       weighted ? 1 : 0, scale, loo_first, buf.p, Rp, Kp);
+                       weighted ? 1 : 0, scale, loo_first, row_ids, buf.p, Rp, Kp);
   else
     hipLaunchKernelGGL(dense_planes_kernel<3>, grid, dim3(256), 0, ctx().stream, S, ld, row0, rows, K, alpha,
-                       weighted ? 1 : 0, scale, loo_first, buf.p, Rp, Kp);
+                       weighted ? 1 : 0, scale, loo_first, row_ids, buf.p, Rp, Kp);
   SS_LAUNCH_CHECK();
   *Rp_out = Rp;
   *Kp_out = Kp;
@@ -387,13 +388,14 @@ static int make_planes(const float* S, int64_t ld, int64_t row0, int64_t rows, i
 }
 
 int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
-                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows) {
+                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows,
+                               const int* row_ids) {
   if (nrows <= 0 || d.ns <= 0) return SS_OK;
   // source side: once per graph (alpha and the weighting are fixed in the handle)
   const int npb = d.weighted ? 3 : 1;
   int64_t Np = 0, Kp = 0;
   if (d.Bpl_np != npb) {
-    SS_TRY(make_planes(d.Ss.p, d.ns, 0, d.ns, d.nf, d.alpha, d.weighted, nullptr, -1, npb, d.Bpl, &Np, &Kp));
+    SS_TRY(make_planes(d.Ss.p, d.ns, 0, d.ns, d.nf, d.alpha, d.weighted, nullptr, -1, nullptr, npb, d.Bpl, &Np, &Kp));
     d.Bpl_np = npb;
     d.Bpl_Np = Np;
     d.Bpl_Kp = Kp;
@@ -402,9 +404,10 @@ int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k,
   Kp = d.Bpl_Kp;
   // query side: this block of rows, threshold * 1/kf (LOO: 1/(kf-1), own feature dropped)
   int64_t Mp = 0, Kp2 = 0;
-  const bool from_ss = loo || source_rows;  // rows of the source similarity itself (LOO: own feature dropped)
+  // rows of the source similarity itself (LOO: own feature dropped; k-fold: the members row_ids[row_begin ...])
+  const bool from_ss = loo || source_rows || row_ids != nullptr;
   SS_TRY(make_planes(from_ss ? d.Ss.p : d.Sq.p, from_ss ? d.ns : d.nq, row_begin, nrows, d.nf, d.alpha, d.weighted,
-                     inv_k, loo ? row_begin : -1, 3, d.Apl, &Mp, &Kp2));
+                     inv_k, loo ? row_begin : -1, row_ids, 3, d.Apl, &Mp, &Kp2));
   DenseBf16Args a{};
   a.A = d.Apl.p;
   a.B = d.Bpl.p;

@@ -212,7 +212,9 @@ int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k
 int dense_degrees(Graph<float>& g);
 // dense_bf16.hip: the same product on the bf16 matrix cores with the operands split into exact bf16 planes
 int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
-                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows = false);
+                               int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows = false,
+                               const int* row_ids = nullptr);
+int dense_fold_degrees(const Graph<float>& g, const int* members, int64_t nm, int* kf, int* ks, int* kt);
 
 template <class T>
 int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout);

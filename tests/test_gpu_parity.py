@@ -610,3 +610,22 @@ def test_jaccard_similarity_shapes_and_zero_rows():
     got = ss.jaccard_similarity(torch.from_numpy(X.astype(np.float32)).cuda())
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=3e-6)
     assert ss.jaccard_similarity(np.zeros((0, 4))).shape == (0, 0)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_dense_similarity_kfold_equals_sparse_kfold(weighted):
+    """k-fold in the dense regime (per-fold degree recount on the dense matrix, members' rows gathered into the
+    query planes) against the sparse k-fold path on the same thresholded input."""
+    rng = np.random.default_rng(31)
+    ns, nt, k = 333, 29, 4
+    Ss = rng.random((ns, ns)).astype(np.float32); Ss = ((Ss + Ss.T) / 2).astype(np.float32); np.fill_diagonal(Ss, 1.0)
+    Y = (rng.random((ns, nt)) < 0.08).astype(np.float32)
+    Y[:, 5] = 0; Y[10, 5] = 1; Y[20, 5] = 1            # a target whose edges all sit in one fold -> clean!
+    fold = rng.integers(0, k, size=ns).astype(np.int32); fold[10] = fold[20] = 1
+    alpha = 0.6
+    dense = ss.DeviceGraph.from_similarity(None, Ss, sp.csr_matrix(Y), alpha=alpha, weighted=weighted)
+    sparse = ss.DeviceGraph.from_dense(None, Ss, Y, alpha=np.float32(alpha), weighted=weighted, dtype=np.float64)
+    want = sparse.predict_kfold(fold, k, clean=True)
+    got = dense.predict_kfold(fold, k, clean=True)
+    assert ((want == -99) == (got == -99)).all() and (want[10] == -99).any()
+    assert_close(got, want, np.float32)
