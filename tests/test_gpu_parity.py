@@ -629,3 +629,13 @@ def test_dense_similarity_kfold_equals_sparse_kfold(weighted):
     got = dense.predict_kfold(fold, k, clean=True)
     assert ((want == -99) == (got == -99)).all() and (want[10] == -99).any()
     assert_close(got, want, np.float32)
+
+
+def test_tutorial_example_runs_end_to_end_on_the_device():
+    import importlib.util
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "iris_tutorial.py")
+    spec = importlib.util.spec_from_file_location("iris_tutorial", p)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    out = mod.main(0.9)
+    for weighted in (True, False):
+        assert out[weighted]["AuROC"] > 0.9 and out[weighted]["accuracy_of_predicted"] > 0.9   # iris is easy
