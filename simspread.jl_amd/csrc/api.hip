@@ -729,7 +729,7 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   }
   hipEvent_t e_begin, e_end;
   SS_TRY(timing_mark(&e_begin));
-  // row-major operands: B <= 8 streams W once with R chunks in LDS (HBM-bound kernel); 32 < B <= 64 goes, by
+  // row-major operands: B <= 7 streams W once with R chunks in LDS (HBM-bound kernel); 32 < B <= 64 goes, by
   // default, to the wide LDS-tiled kernel with the slices split over workgroups (W is then streamed B/4 times:
   // measured at 100k x 100k / 1 %: B=64 1.18 ms vs 4.9 ms for the register-accumulator kernel
   // (SS_NARROW_REGACC=1) and 5.6 ms for gathering rows of R from L2 (SS_NARROW_CSR=1))
@@ -784,7 +784,7 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
     SS_TRY(launch_spmm_chunked_narrow<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
     timing_count(ST_NSPMM, 1);
   } else if (narrow && std::is_same<T, float>::value && !use_csr_gather) {
-    // 16 < B <= 64: accumulators in registers, R chunks in LDS, W read once
+    // comparison kernel (SS_NARROW_REGACC=1), 16 < B <= 64: accumulators in registers, R chunks in LDS, W read once
     if constexpr (std::is_same<T, float>::value) {
       if (m.pairs.KC == 0) {
         int kc = 640;  // 640 rows x 64 floats = 160 KB

@@ -179,19 +179,19 @@ int sell_max_chunk(int qt);
 template <class T>
 int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T* F, int64_t ldf,
                      const int* clean_deg, const int* out_rows = nullptr);
-// stage 2, narrow (B <= 16): R chunk in LDS, W streamed once from HBM in chunk-major order
+// stage 2, narrow (serves B <= 7 by default, built for B <= 16): R chunk in LDS, W streamed once in chunk-major order
 template <class T>
 int narrow_chunk_cols(int bv);  // KC for a padded width bv
 template <class T>
 int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
                                DevBuf<T>& partial);
-// stage 2, mid width (8 < B <= 32; fp64: <= 16): a workgroup owns rows, accumulators stay in registers while the
+// stage 2, mid width (8 <= B <= 32; fp64: 8 < B <= 16): a workgroup owns rows, accumulators stay in registers while the
 // chunks of R cycle through LDS (spmm_mid.hip); same chunked operand format as the narrow kernel
 template <class T>
 int mid_chunk_cols(int bv);
 template <class T>
 int launch_spmm_rowblock(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
-// stage 2, 16 < B <= 64 (fp32): accumulators in registers (lane = column), R chunk in LDS, entries by s_load
+// comparison kernel (SS_NARROW_REGACC=1), 16 < B <= 64 (fp32): accumulators in registers (lane = column), entries by s_load
 int pairs_build(const DevCsr<float>& in, int KC, int row_bytes, DevPairs& out);
 int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf);
 // stage 2, narrow (B <= 64): F[m][b] = sum_k W[m][k] * R[k][b]   (row-major operands, CSR streamed once)
