@@ -750,7 +750,34 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   const bool narrow = (B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR && !wide_for_mid);
   DevBuf<T> Rt, Ft;
   const bool use_csr_gather = getenv("SS_NARROW_CSR") != nullptr;
-  if (mid) {
+  // 2-D cut with conflict-free gathers (spmm_colgroup.hip): tile rows of 64 .. 256 bytes, i.e. fp32 16 <= B <= 64 (by
+  // default from B = 9, where the 64-byte tile row starts to pay), fp64 up to B = 32.  SS_COL=0: the kernels below
+  int col_from = sizeof(T) == 4 ? 9 : 5;
+  if (const char* e = getenv("SS_COL_FROM")) col_from = atoi(e);
+  // pattern-only W (every value 1) wider than a 128-byte tile row: the wide SELL kernel re-streams only the 2-byte indices
+  // and is faster there (B = 64: 0.61 ms vs 0.82 ms); with values the 2-D kernel wins (0.93 ms vs 1.27 ms)
+  const bool col_wide_ok = !(m.csr.binary && B * (int64_t)sizeof(T) > 128) || getenv("SS_COL_FROM") != nullptr;
+  const bool col = (B >= col_from && B * (int64_t)sizeof(T) <= 256 && col_wide_ok && r_layout == SS_LAYOUT_ROWMAJOR &&
+                    f_layout == SS_LAYOUT_ROWMAJOR && !(getenv("SS_COL") && atoi(getenv("SS_COL")) == 0) &&
+                    getenv("SS_WIDE_FROM") == nullptr && getenv("SS_NARROW_REGACC") == nullptr &&
+                    getenv("SS_NARROW_CSR") == nullptr && getenv("SS_MID_FROM") == nullptr);
+  if (col) {
+    const int rowb = B * (int64_t)sizeof(T) <= 64 ? 64 : (B * (int64_t)sizeof(T) <= 128 ? 128 : 256);
+    const int slot = rowb == 64 ? 0 : (rowb == 128 ? 1 : 3);
+    const int bv = rowb / (int)sizeof(T);
+    DevChunked<T>& op = m.mid[slot];
+    if (op.SC == 0) {
+      int kc = colgroup_chunk_cols<T>(bv);
+      if (const char* e = getenv("SS_NARROW_CHUNK")) {
+        const int v = atoi(e);
+        if (v >= 16 && v < kc) kc = v;
+      }
+      SS_TRY(chunked_build<T>(m.csr, kc, 4, op));
+    }
+    StageTimer t2(ST_SPMM);
+    SS_TRY(launch_spmm_colgroup<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
+    timing_count(ST_NSPMM, 1);
+  } else if (mid) {
     // 32-byte tile rows (8 floats), 64-byte (16 floats) or 128-byte (32 floats, 16 doubles)
     const int rowb = (B * (int64_t)sizeof(T) <= 32 && sizeof(T) == 4) ? 32 : ((B <= 16 && sizeof(T) == 4) ? 64 : 128);
     const int slot = rowb == 32 ? 2 : (rowb == 64 ? 0 : 1);

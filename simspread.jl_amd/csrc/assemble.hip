@@ -731,10 +731,11 @@ __global__ void chunk_count_kernel(const int* __restrict__ ptr, const int* __res
 }
 
 // wave per (chunk, row): copy the sub-row with chunk-local indices, padded to whole units
+constexpr int CHUNK_SCHED_ITERS = 4;  // sub-rows of up to 256 entries are bank-scheduled, longer ones copied in order
 template <class T>
 __global__ void chunk_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
-                                  int64_t rows, int SC, int nchunks, int align, const int* __restrict__ off,
-                                  unsigned short* __restrict__ oidx, T* __restrict__ oval) {
+                                  int64_t rows, int SC, int nchunks, int align, int sched,
+                                  const int* __restrict__ off, unsigned short* __restrict__ oidx, T* __restrict__ oval) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -753,6 +754,56 @@ __global__ void chunk_fill_kernel(const int* __restrict__ ptr, const int* __rest
     b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
     const int n = a - first;
+    if (sched && align == 1 && n > 32 && n <= 64 * CHUNK_SCHED_ITERS) {
+      // Bank schedule (stage-1 operand only).  The transfer kernel folds a sub-row into its LDS accumulators 64
+      // entries per read-add-write, which the LDS serves in two groups of 32 lanes, one cycle per group when the
+      // 32 addresses fall into different banks (bank = column mod 32) and one more for every extra address on a
+      // busy bank.  The columns of a sub-row are distinct, so their order is free: sort the entries by bank and
+      // deal them round-robin over the G = ceil(n/32) lane groups -- a bank then meets a group twice only when
+      // more than G of the sub-row's columns share it.  The last group holds the remainder L = n - 32(G-1): the
+      // first L*G entries go round all G groups, the rest round the first G-1.
+      const int G = (n + 31) >> 5;
+      const int L = n - 32 * (G - 1);
+      int cnt = 0;  // lane b < 32: entries of the sub-row in bank b
+      int bank[CHUNK_SCHED_ITERS], col[CHUNK_SCHED_ITERS];
+#pragma unroll
+      for (int j = 0; j < CHUNK_SCHED_ITERS; ++j) {
+        const int x = lane + 64 * j;
+        col[j] = x < n ? (int)(idx[first + x] - k0) : -1;
+        bank[j] = x < n ? (col[j] & 31) : -1;
+      }
+      for (int b = 0; b < 32; ++b) {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < CHUNK_SCHED_ITERS; ++j) c += __popcll(__ballot(bank[j] == b));
+        if (lane == b) cnt = c;
+      }
+      int base = 0;  // exclusive prefix of cnt over the banks
+      for (int b = 0; b < 31; ++b) {
+        const int c = __builtin_amdgcn_readlane(cnt, b);
+        if (lane > b) base += c;
+      }
+      int run = 0;  // lane b: entries of bank b placed so far
+#pragma unroll
+      for (int j = 0; j < CHUNK_SCHED_ITERS; ++j) {
+        int p = -1;
+        for (int b = 0; b < 32; ++b) {
+          const unsigned long long m = __ballot(bank[j] == b);
+          const int bb = __builtin_amdgcn_readlane(base, b) + __builtin_amdgcn_readlane(run, b);
+          if (bank[j] == b) p = bb + __popcll(m & ((1ull << lane) - 1ull));
+          if (lane == b) run += __popcll(m);
+        }
+        if (p >= 0) {
+          int grp, slot;
+          if (p < L * G) { grp = p % G; slot = p / G; }
+          else { const int q = p - L * G; grp = q % (G - 1); slot = L + q / (G - 1); }
+          const int pos = grp * 32 + slot;
+          oidx[o + pos] = (unsigned short)col[j];
+          oval[o + pos] = val[first + lane + 64 * j];
+        }
+      }
+      continue;
+    }
     for (int x = lane; x < npad; x += 64) {
       oidx[o + x] = x < n ? (unsigned short)(idx[first + x] - k0) : (unsigned short)SC;  // SC = zero sentinel
       oval[o + x] = x < n ? val[first + x] : T(0);
@@ -797,8 +848,10 @@ int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out) {
   SS_TRY(out.val.alloc(out.stored + 64));
   SS_HIP(hipMemsetAsync(out.idx.p + out.stored, 0, 64 * sizeof(unsigned short), st));
   SS_HIP(hipMemsetAsync(out.val.p + out.stored, 0, 64 * sizeof(T), st));
+  // entry order inside a sub-row: bank-scheduled for the stage-1 operand (align 1) unless SS_CHUNK_SCHED=0
+  const int sched = (align == 1 && !(getenv("SS_CHUNK_SCHED") && atoi(getenv("SS_CHUNK_SCHED")) == 0)) ? 1 : 0;
   hipLaunchKernelGGL(chunk_fill_kernel<T>, dim3(grid_for(total * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p,
-                     in.val.p, in.rows, SC, out.nchunks, align, out.off.p, out.idx.p, out.val.p);
+                     in.val.p, in.rows, SC, out.nchunks, align, sched, out.off.p, out.idx.p, out.val.p);
   SS_LAUNCH_CHECK();
   SS_HIP(hipStreamSynchronize(st));
   return SS_OK;

@@ -112,7 +112,7 @@ struct SpMat {
   DevSell<T> sell;
   int sell_qt = 0;
   DevChunked<T> narrow[5];  // quad-aligned chunked operands for B <= 1, 2, 4, 8, 16 (built lazily)
-  DevChunked<T> mid[3];     // operands of the mid-width kernel: 64-, 128- and 32-byte tile rows (built lazily)
+  DevChunked<T> mid[4];     // operands of the mid-width kernels: 64-, 128-, 32- and 256-byte tile rows (built lazily)
   DevPairs pairs;           // operand of the register-accumulator kernel (16 < B <= 64, fp32)
   DevBuf<T> partial;        // [nchunks][rows][BV] partial sums of the narrow kernel
 };
@@ -191,6 +191,13 @@ template <class T>
 int mid_chunk_cols(int bv);
 template <class T>
 int launch_spmm_rowblock(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
+// stage 2, mid width, 2-D cut (row blocks x chunk groups) with conflict-free gathers (spmm_colgroup.hip): tile rows of
+// 64, 128 or 256 bytes (fp32: B <= 16, 32, 64; fp64: B <= 8, 16, 32); same chunked operand
+template <class T>
+int colgroup_chunk_cols(int bv);
+template <class T>
+int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
+                         DevBuf<T>& partial);
 // comparison kernel (SS_NARROW_REGACC=1), 16 < B <= 64 (fp32): accumulators in registers (lane = column), entries by s_load
 int pairs_build(const DevCsr<float>& in, int KC, int row_bytes, DevPairs& out);
 int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf);

@@ -192,21 +192,47 @@ __device__ __forceinline__ void subrows_load(SubRows<T, U>& s, int first, int b_
   }
 }
 
-template <class T, int U>
+// DUAL: two copies of the accumulators (acc and acc + astride); sub-rows 2i and 2i+1 of a batch go to different
+// copies, so their read-add-write pairs are independent and both LDS reads are in flight together (with one copy
+// every pair waits for the previous pair's LDS round trip).  The copies are added when T is written out: the sum
+// order is still fixed.
+template <class T, int U, bool DUAL>
 __device__ __forceinline__ void subrows_fold(const SubRows<T, U>& s, int first, int b_l, int n_l, T cf_l,
-                                             T* __restrict__ acc, int dummy,
+                                             T* __restrict__ acc, int astride, int dummy,
                                              const unsigned short* __restrict__ midx, const T* __restrict__ mval,
                                              int lane) {
   int nmax = 0;
+  if constexpr (DUAL) {
+    T* __restrict__ acc1 = acc + astride;
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int j = lane < s.n[u] ? (int)s.j[u] : dummy;
-    acc[j] = fma(s.cf[u], s.v[u], acc[j]);
-    if (s.n[u] > 64) {
-      const int k = 64 + lane < s.n[u] ? (int)s.j2[u] : dummy;
-      acc[k] = fma(s.cf[u], s.v2[u], acc[k]);
+    for (int u = 0; u < U; u += 2) {
+      const int ja = lane < s.n[u] ? (int)s.j[u] : dummy;
+      const int jb = lane < s.n[u + 1] ? (int)s.j[u + 1] : dummy;
+      const T ra = acc[ja], rb = acc1[jb];
+      acc[ja] = fma(s.cf[u], s.v[u], ra);
+      acc1[jb] = fma(s.cf[u + 1], s.v[u + 1], rb);
+      if (s.n[u] > 64 || s.n[u + 1] > 64) {
+        const int ka = (s.n[u] > 64 && 64 + lane < s.n[u]) ? (int)s.j2[u] : dummy;
+        const int kb = (s.n[u + 1] > 64 && 64 + lane < s.n[u + 1]) ? (int)s.j2[u + 1] : dummy;
+        const T va = s.n[u] > 64 ? s.v2[u] : T(0), vb = s.n[u + 1] > 64 ? s.v2[u + 1] : T(0);
+        const T qa = acc[ka], qb = acc1[kb];
+        acc[ka] = fma(s.cf[u], va, qa);
+        acc1[kb] = fma(s.cf[u + 1], vb, qb);
+      }
+      nmax = s.n[u] > nmax ? s.n[u] : nmax;
+      nmax = s.n[u + 1] > nmax ? s.n[u + 1] : nmax;
     }
-    nmax = s.n[u] > nmax ? s.n[u] : nmax;
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = lane < s.n[u] ? (int)s.j[u] : dummy;
+      acc[j] = fma(s.cf[u], s.v[u], acc[j]);
+      if (s.n[u] > 64) {
+        const int k = 64 + lane < s.n[u] ? (int)s.j2[u] : dummy;
+        acc[k] = fma(s.cf[u], s.v2[u], acc[k]);
+      }
+      nmax = s.n[u] > nmax ? s.n[u] : nmax;
+    }
   }
   if (nmax > 128) {  // rare: a sub-row longer than two waves (bounds re-read by lane index, no register arrays)
 #pragma unroll 1
@@ -222,12 +248,14 @@ __device__ __forceinline__ void subrows_fold(const SubRows<T, U>& s, int first, 
   }
 }
 
-template <class T, bool LOO, int U, bool BINM>
+template <class T, bool LOO, int U, bool BINM, bool DUAL>
 __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs<T> p) {
   static_assert(64 % (2 * U) == 0, "U must divide 32");
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* acc = reinterpret_cast<T*>(smem_raw);                        // [SC] sums + [64] per-lane dummies
-  unsigned* bits = reinterpret_cast<unsigned*>(acc + p.SC + 64);  // LOO only: source owns the dropped feature
+  T* acc = reinterpret_cast<T*>(smem_raw);                        // [SC] sums + [64] per-lane dummies (x2 when DUAL)
+  const int astride = p.SC + 64;
+  constexpr int NCOPY = DUAL ? 2 : 1;
+  unsigned* bits = reinterpret_cast<unsigned*>(acc + NCOPY * astride);  // LOO only: source owns the dropped feature
   const int lane = threadIdx.x;
   const int c = blockIdx.x % p.nchunks;
   const int64_t r = blockIdx.x / p.nchunks;
@@ -236,7 +264,7 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
   const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
   const int dummy = p.SC + lane;
 
-  for (int j = lane; j < p.SC + 64; j += 64) acc[j] = T(0);
+  for (int j = lane; j < NCOPY * astride; j += 64) acc[j] = T(0);
   if (LOO)
     for (int j = lane; j < (p.SC + 31) / 32; j += 64) bits[j] = 0u;
   __syncthreads();
@@ -270,10 +298,10 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
       subrows_load<T, U, BINM>(A, 0, b_l, n_l, cf_l, midx, mval, lane);
       for (int u0 = 0; u0 < cnt; u0 += 2 * U) {
         if (u0 + U < cnt) subrows_load<T, U, BINM>(B, u0 + U, b_l, n_l, cf_l, midx, mval, lane);
-        subrows_fold<T, U>(A, u0, b_l, n_l, cf_l, acc, dummy, midx, mval, lane);
+        subrows_fold<T, U, DUAL>(A, u0, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
         if (u0 + U < cnt) {
           if (u0 + 2 * U < cnt) subrows_load<T, U, BINM>(A, u0 + 2 * U, b_l, n_l, cf_l, midx, mval, lane);
-          subrows_fold<T, U>(B, u0 + U, b_l, n_l, cf_l, acc, dummy, midx, mval, lane);
+          subrows_fold<T, U, DUAL>(B, u0 + U, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
         }
       }
     }
@@ -292,11 +320,12 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
   T* orow = p.out + r * p.ld + j0;
   for (int j = lane; j < jn; j += 64) {
     T z;
+    const T sum = DUAL ? acc[j] + acc[astride + j] : acc[j];
     if (LOO) {
       const int d = p.ks[j0 + j] - (int)((bits[j >> 5] >> (j & 31)) & 1u);
-      z = (d > 0 && (j0 + j) != gr) ? acc[j] * (T(1) / T(d)) : T(0);
+      z = (d > 0 && (j0 + j) != gr) ? sum * (T(1) / T(d)) : T(0);
     } else {
-      z = acc[j] * p.inv2[j0 + j];
+      z = sum * p.inv2[j0 + j];
       if (p.accumulate) z += orow[j];
     }
     orow[j] = z;
@@ -304,6 +333,39 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
 }
 
 constexpr int TRANSFER_U = 8;
+
+// SS_TRANSFER_DUAL=0/1: one or two copies of the LDS accumulators (see subrows_fold)
+static bool transfer_dual() {
+  const char* e = getenv("SS_TRANSFER_DUAL");
+  return e ? atoi(e) != 0 : false;
+}
+
+static int transfer_u() {
+  const char* e = getenv("SS_TRANSFER_U");
+  const int u = e ? atoi(e) : TRANSFER_U;
+  return (u == 4 || u == 16) ? u : 8;
+}
+
+template <class T, bool LOO>
+static int launch_transfer_variant(const TransferArgs<T>& p, unsigned grid, size_t lds, bool binm, bool dual) {
+#define SS_TRANSFER_LAUNCH(U, BINM, DUAL)                                                               \
+  hipLaunchKernelGGL((transfer_kernel<T, LOO, U, BINM, DUAL>), dim3(grid), dim3(TRANSFER_THREADS), lds, \
+                     ctx().stream, p)
+#define SS_TRANSFER_U(U)                                                                      \
+  do {                                                                                        \
+    if (binm) { if (dual) SS_TRANSFER_LAUNCH(U, true, true); else SS_TRANSFER_LAUNCH(U, true, false); } \
+    else { if (dual) SS_TRANSFER_LAUNCH(U, false, true); else SS_TRANSFER_LAUNCH(U, false, false); }    \
+  } while (0)
+  switch (transfer_u()) {
+    case 4: SS_TRANSFER_U(4); break;
+    case 16: SS_TRANSFER_U(16); break;
+    default: SS_TRANSFER_U(8); break;
+  }
+#undef SS_TRANSFER_U
+#undef SS_TRANSFER_LAUNCH
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
 
 template <class T>
 int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
@@ -330,16 +392,11 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
   p.accumulate = accumulate ? 1 : 0;
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
-  const size_t lds = (size_t)(p.SC + 64) * sizeof(T);
   bool binm = true;
   for (int t = 0; t < nterms; ++t) binm = binm && Mt[t]->binary;
-  if (binm)
-    hipLaunchKernelGGL((transfer_kernel<T, false, TRANSFER_U, true>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
-                       ctx().stream, p);
-  else
-    hipLaunchKernelGGL((transfer_kernel<T, false, TRANSFER_U, false>), dim3((unsigned)grid), dim3(TRANSFER_THREADS),
-                       lds, ctx().stream, p);
-  SS_LAUNCH_CHECK();
+  const bool dual = transfer_dual();
+  const size_t lds = (size_t)(p.SC + 64) * sizeof(T) * (dual ? 2 : 1);
+  SS_TRY((launch_transfer_variant<T, false>(p, (unsigned)grid, lds, binm, dual)));
   return SS_OK;
 }
 
@@ -361,14 +418,9 @@ int launch_transfer_loo(const DevCsr<T>& X, const DevChunked<T>& XT, const int* 
   p.ld = ld;
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
-  const size_t lds = (size_t)(p.SC + 64) * sizeof(T) + (size_t)((p.SC + 31) / 32) * 4;
-  if (XT.binary)
-    hipLaunchKernelGGL((transfer_kernel<T, true, TRANSFER_U, true>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
-                       ctx().stream, p);
-  else
-    hipLaunchKernelGGL((transfer_kernel<T, true, TRANSFER_U, false>), dim3((unsigned)grid), dim3(TRANSFER_THREADS), lds,
-                       ctx().stream, p);
-  SS_LAUNCH_CHECK();
+  const bool dual = transfer_dual();
+  const size_t lds = (size_t)(p.SC + 64) * sizeof(T) * (dual ? 2 : 1) + (size_t)((p.SC + 31) / 32) * 4;
+  SS_TRY((launch_transfer_variant<T, true>(p, (unsigned)grid, lds, XT.binary, dual)));
   return SS_OK;
 }
 

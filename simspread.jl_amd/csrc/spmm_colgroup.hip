@@ -1,0 +1,447 @@
+// Stage 2, mid width (16 <= B <= 64 columns of R, fp32; 8 <= B <= 32, fp64): F = W*R with a 2-D cut of the work
+// and bank-conflict-free gathers.
+//
+// The row-block kernel (spmm_mid.hip) gives every CU its own rows and makes it walk ALL chunks of R, so R is
+// restaged 256 times (B = 64, K = 100k: 6.5 GB of L2 -> LDS traffic for a 0.85 GB problem), and its lanes gather
+// rows of the tile at random 16-byte slots (2.5-3 LDS cycles per ds_read_b128 instead of 1).  Here
+//
+//  * the grid is RB row blocks x CG chunk groups: workgroup (rb, cg) owns rows_per_wg rows (accumulators in
+//    registers for as many rows as the register file holds: 8 waves x NP x 16 rows) and walks only the chunks
+//    c = cg, cg + CG, ...; R is restaged RB times instead of 256, and the CG partial sums per row are combined
+//    in fixed order by narrow_reduce_kernel (CG = 1: written directly).  RB and CG are chosen per launch so that
+//    RB*CG fills the CUs and RB*|R| + 2*CG*|F| is smallest;
+//  * four lanes share a non-zero and a wave works on 16 rows at once (lane group j = lane / 4, row = base + j).
+//    The tile row of a non-zero (ROWB = 64, 128 or 256 bytes) is read as NR = ROWB/64 ds_read_b128 per lane.
+//    A ds_read_b128 is served in four groups of 16 lanes, {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same
+//    +32 (MI355X_MICROARCH.md, LDS), i.e. lane groups {j0,j3,j5,j6} and {j1,j2,j4,j7}: in read r lane group j
+//    fetches the 64-byte quarter (r ^ rot_j) of its tile row with rot_j = (j & 7) >> 1, so the four non-zeros of
+//    a hardware group always sit in four different quarters of the 256-byte LDS line -- with 256-byte tile rows
+//    (B = 64) every gather is conflict-free whatever the column indices are; with 128- and 64-byte rows two or four
+//    tile rows share a line and the position also depends on the index (1.75 / 2.1 cycles on random indices);
+//  * same chunked operand as the narrow and row-block kernels (16-bit chunk-local indices, quads, W streamed
+//    once), tile restaged per chunk by LDS-DMA; every sum has a fixed order.
+#include "graph.hpp"
+
+namespace ss {
+
+#define SS_LAUNCH_CHECK()                                                             \
+  do {                                                                                \
+    hipError_t _e = hipGetLastError();                                                \
+    if (_e != hipSuccess)                                                             \
+      return fail(SS_EHIP, "%s:%d kernel launch: %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+  } while (0)
+
+template <class T>
+struct ColArgs {
+  const int* off;             // [nchunks][M] (+1) in quads
+  const unsigned short* idx;  // quads of chunk-local indices (pad = KC -> zero tile row)
+  const T* val;
+  int64_t M, K;
+  int KC, nchunks, B;
+  const T* R;  // row-major [K][ldr]
+  int64_t ldr;
+  T* F;        // row-major [M][ldf]; used when CG == 1
+  int64_t ldf;
+  T* P;        // [CG][M][BV] partial sums when CG > 1
+  int rows_per_wg, RBn, CG, np_used;
+  int vec_ok;
+  int dbg;  // SS_COL_DBG ablations (timing experiments only; results are wrong): 1 no tile staging, 2 no gathers
+};
+
+__device__ __attribute__((aligned(16))) unsigned int col_zero[4] = {0u, 0u, 0u, 0u};
+
+constexpr int COL_ROWS = 16;      // rows per wave step (four lanes per row)
+#ifndef COL_AHEAD_OVERRIDE
+#define COL_AHEAD_OVERRIDE 0
+#endif
+
+template <class T, int N>
+struct alignas(16) ColPack {
+  T v[N];
+};
+
+// DPP quad_perm inside each group of four lanes: CTRL 0x00 = every lane takes lane 0's value (broadcast),
+// 0x39 = lane i takes lane (i + 1) % 4's value (rotate)
+template <class T, int CTRL>
+__device__ __forceinline__ T dpp_quad(T v);
+template <> __device__ __forceinline__ float dpp_quad<float, 0x00>(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x00, 0xF, 0xF, true)); }
+template <> __device__ __forceinline__ float dpp_quad<float, 0x39>(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x39, 0xF, 0xF, true)); }
+#define SS_DPP_F64(CTRL)                                                                           \
+  template <> __device__ __forceinline__ double dpp_quad<double, CTRL>(double v) {                 \
+    const long long b = __double_as_longlong(v);                                                   \
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true); \
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);          \
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);                         \
+  }
+SS_DPP_F64(0x00) SS_DPP_F64(0x39)
+#undef SS_DPP_F64
+
+template <class T, int BV, int NP, bool BIN, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) spmm_colgroup_kernel(ColArgs<T> a) {
+  constexpr int COL_THREADS = WAVES * 64;    // 16 waves: 128 VGPRs per lane, 8 waves: 256
+  constexpr int PW = 16 / (int)sizeof(T);    // values per 16-byte slot
+  constexpr int ROWB = BV * (int)sizeof(T);  // bytes per tile row: 64, 128 or 256
+  constexpr int NR = ROWB / 64;              // ds_read_b128 per non-zero and lane
+  constexpr int RSH = ROWB == 256 ? 8 : (ROWB == 128 ? 7 : 6);
+  constexpr int NCG = ROWB / 16;             // 16-byte slots per tile row
+  constexpr int CPL = NR * PW;               // columns per lane
+  constexpr int NBQ = ROWB == 64 ? 2 : 1;    // batches of four quads requested ahead per row (mean sub-row: 23 / 12 / 6 entries)
+  // row sets whose first batches are in flight (measured at 100k x 100k, 1 %: 1, 2 and 3 differ by < 5 % -- the kernel is
+  // bound by instruction issue, not by the latency of the W stream)
+  constexpr int AHEAD = COL_AHEAD_OVERRIDE ? COL_AHEAD_OVERRIDE : (BIN ? 2 : 1);
+  static_assert(ROWB == 64 || ROWB == 128 || ROWB == 256, "tile row must be 64, 128 or 256 bytes");
+  using P = ColPack<T, PW>;
+  using Q = ColPack<T, 4>;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  unsigned char* const tb = smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane >> 2, cl = lane & 3;
+  const int rot = ((j & 7) >> 1) & (NR - 1);
+  unsigned sl[NR];  // byte offset inside the tile row of read r
+#pragma unroll
+  for (int r = 0; r < NR; ++r) sl[r] = (unsigned)((cl + 4 * (r ^ rot)) * 16);
+
+  const int rb = blockIdx.x % a.RBn, cg = blockIdx.x / a.RBn;
+  const int64_t r0 = (int64_t)rb * a.rows_per_wg;
+  const int64_t rend = (r0 + a.rows_per_wg < a.M) ? r0 + a.rows_per_wg : a.M;
+  const int64_t wrow0 = r0 + (int64_t)wave * (NP * COL_ROWS);
+
+  T acc[NP][CPL];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[p][i] = T(0);
+
+  const uint2* __restrict__ ip = reinterpret_cast<const uint2*>(a.idx);
+  const Q* __restrict__ vp = reinterpret_cast<const Q*>(a.val);
+
+  // one non-zero: tile row k, weight wv, into row set p
+  auto entry = [&](int p, unsigned k, T wv) __attribute__((always_inline)) {
+    const unsigned base = k << RSH;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const P t = *reinterpret_cast<const P*>(tb + base + sl[r]);
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        if (BIN) acc[p][r * PW + i] += t.v[i];
+        else acc[p][r * PW + i] = fma(wv, t.v[i], acc[p][r * PW + i]);
+      }
+    }
+  };
+
+  // LDS: the tile [KC + 1][ROWB], then two buffers for the sub-row bounds of this workgroup's rows.  The bounds
+  // off[r0 .. r0 + rows_per_wg] of a chunk are read once (coalesced LDS-DMA) instead of by four lanes each, and one
+  // chunk AHEAD, in the same staging phase as the tile of the chunk before: no LDS-DMA is ever in flight during a
+  // gather phase (the compiler cannot tell LDS regions apart and would drain vmcnt(0), i.e. every prefetched quad, in
+  // front of each LDS read while one is).
+  const int obuf = (a.rows_per_wg + 1 + 3) & ~3;
+  int* const offs0 = reinterpret_cast<int*>(tb + (size_t)(a.KC + 1) * ROWB);
+  const int lrow0 = wave * (NP * COL_ROWS) + j;  // workgroup-local row of row set 0
+  auto stage_bounds = [&](int c, int* dst) __attribute__((always_inline)) {
+    const int* __restrict__ off = a.off + (int64_t)c * a.M;
+    for (int base = (tid >> 6) * 64; base <= a.rows_per_wg; base += COL_THREADS) {
+      const int i = base + (tid & 63);
+      if (i <= a.rows_per_wg) {
+        const int64_t m = (r0 + i < rend) ? r0 + i : rend;   // rows past the block: empty sub-rows
+        __builtin_amdgcn_global_load_lds((const void*)(off + m), (__attribute__((address_space(3))) void*)(dst + base), 4, 0, 0);
+      }
+    }
+  };
+  if (cg < a.nchunks) stage_bounds(cg, offs0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int it = 0;
+  for (int c = cg; c < a.nchunks; c += a.CG, ++it) {
+    const int64_t k0 = (int64_t)c * a.KC;
+    const int kn = (int)((a.K - k0 < a.KC) ? (a.K - k0) : a.KC);
+    const int* const offs = offs0 + (it & 1) * obuf;
+
+    __syncthreads();  // everybody is done with the previous tile
+
+    // The four lanes of a row load four CONSECUTIVE quads of its sub-row (lane cl: quad q + cl), NBQ such batches per
+    // row set, AHEAD row sets before the gathers that use them: one load instruction per batch brings 16 entries per
+    // row.  A quad is then broadcast inside its group of four lanes by DPP quad_perm (no LDS traffic).  Loads are
+    // unconditional (clamped to a valid quad: the operand carries 64 entries of slack) so that they stay out of
+    // branches.  The first AHEAD row sets are requested BEFORE the tile is restaged: their latency overlaps the staging.
+    int bq[NP], be[NP];
+    uint2 fi[NP][NBQ];
+    Q fw[NP][NBQ];
+    auto issue = [&](int p) __attribute__((always_inline)) {
+      const int lr = lrow0 + p * COL_ROWS;
+      bq[p] = offs[lr];
+      be[p] = offs[lr + 1];
+#pragma unroll
+      for (int nb = 0; nb < NBQ; ++nb) {
+        const int x = bq[p] + nb * 4 + cl;
+        const int xx = x < be[p] ? x : bq[p];
+        fi[p][nb] = ip[xx];
+        if (!BIN) fw[p][nb] = vp[xx];
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < AHEAD && p < NP; ++p) issue(p);
+
+    // LDS-DMA: a wave instruction fills 64 consecutive pieces of the tile; pieces outside R read a zero word
+    const unsigned char* rbase = reinterpret_cast<const unsigned char*>(a.R + k0 * a.ldr);
+    const int64_t rowstride = a.ldr * (int64_t)sizeof(T);
+    if (a.dbg & 1) {
+    } else if (a.vec_ok) {
+      const int pieces = (a.KC + 1) * NCG;
+      const int bslots = a.B / PW;
+      for (int base = (tid >> 6) * 64; base < pieces; base += COL_THREADS) {
+        const int pc = base + (tid & 63);
+        if (pc < pieces) {
+          const int k = pc / NCG, slot = pc % NCG;
+          const void* src = (k < kn && slot < bslots) ? (const void*)(rbase + k * rowstride + slot * 16) : (const void*)col_zero;
+          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(tb + (size_t)base * 16), 16, 0, 0);
+        }
+      }
+    } else {
+      constexpr int WPR = ROWB / 4;
+      const int words = (a.KC + 1) * WPR;
+      const int bwords = a.B * ((int)sizeof(T) / 4);
+      for (int base = (tid >> 6) * 64; base < words; base += COL_THREADS) {
+        const int pc = base + (tid & 63);
+        if (pc < words) {
+          const int k = pc / WPR, wc = pc % WPR;
+          const void* src = (k < kn && wc < bwords) ? (const void*)(rbase + k * rowstride + wc * 4) : (const void*)col_zero;
+          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(tb + (size_t)base * 4), 4, 0, 0);
+        }
+      }
+    }
+    if (c + a.CG < a.nchunks) stage_bounds(c + a.CG, offs0 + ((it + 1) & 1) * obuf);  // next chunk's bounds
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // gathers of one batch of (up to four) quads held by lanes cl = 0 .. nq-1 of each group: a rolled loop broadcasts
+    // lane 0's quad and then rotates the quads of the group by one lane (DPP quad_perm, no LDS traffic).  No memory
+    // loads in here: the waits for the prefetched quads stay counted (a load inside would turn them into vmcnt(0))
+    auto batch = [&](int p, int nq, uint2 iv, Q w) __attribute__((always_inline)) {
+      if (a.dbg & 2) { acc[p][0] += __uint_as_float(iv.x) + (BIN ? T(0) : w.v[0]); nq = 0; }
+      for (int e = 0; e < nq; ++e) {
+        const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.x, 0x00, 0xF, 0xF, true);
+        const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.y, 0x00, 0xF, 0xF, true);
+        T w0 = T(0), w1 = T(0), w2 = T(0), w3 = T(0);
+        if (!BIN) {
+          w0 = dpp_quad<T, 0x00>(w.v[0]); w1 = dpp_quad<T, 0x00>(w.v[1]);
+          w2 = dpp_quad<T, 0x00>(w.v[2]); w3 = dpp_quad<T, 0x00>(w.v[3]);
+        }
+        entry(p, x & 0xffffu, w0);
+        entry(p, x >> 16, w1);
+        // weighted variants: keep the scheduler from gathering all four tile rows (up to 64 registers) at once
+        if (!BIN) __builtin_amdgcn_sched_barrier(0);
+        entry(p, y & 0xffffu, w2);
+        entry(p, y >> 16, w3);
+        // rotate: lane cl takes the quad of lane cl + 1
+        iv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.x, 0x39, 0xF, 0xF, true);
+        iv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.y, 0x39, 0xF, 0xF, true);
+        if (!BIN) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w.v[i] = dpp_quad<T, 0x39>(w.v[i]);
+        }
+      }
+    };
+    bool longer = false;  // some row of this lane group has more quads in this chunk than were prefetched
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (p + AHEAD < NP) issue(p + AHEAD);
+      const int nquads = be[p] - bq[p];
+      longer = longer || nquads > NBQ * 4;
+#pragma unroll
+      for (int nb = 0; nb < NBQ; ++nb) {
+        int nq = nquads - nb * 4;
+        nq = nq > 4 ? 4 : nq;
+        batch(p, nq, fi[p][nb], fw[p][nb]);
+      }
+    }
+    // Sub-rows longer than the prefetched batches (a few per cent of the rows on Poisson lengths): one rolled pass over
+    // the row sets with its own loads, into a scratch accumulator that is then added to the row set it belongs to.
+    if (__any(longer)) {
+      for (int pp = 0; pp < NP; ++pp) {
+        const int q = offs[lrow0 + pp * COL_ROWS], qend = offs[lrow0 + pp * COL_ROWS + 1];
+        if (!__any(q + NBQ * 4 < qend)) continue;
+        T keep[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { keep[i] = acc[0][i]; acc[0][i] = T(0); }
+        for (int x = q + NBQ * 4; x < qend; x += 4) {
+          const int xx = x + cl < qend ? x + cl : x;
+          const uint2 iv = ip[xx];
+          Q w;
+          if (!BIN) w = vp[xx];
+          int nq = qend - x;
+          nq = nq > 4 ? 4 : nq;
+          batch(0, nq, iv, w);
+        }
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const T extra = acc[0][i];
+          acc[0][i] = keep[i];
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            if (p == pp) acc[p][i] += extra;
+        }
+      }
+    }
+  }
+
+  // store: read r of lane (j, cl) holds columns (r ^ rot) * 4*PW + cl*PW .. + PW of row wrow0 + p*16 + j
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    {
+      const int64_t m = wrow0 + p * COL_ROWS + j;
+      if (m < rend) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int col = (r ^ rot) * (4 * PW) + cl * PW;
+          if (a.CG > 1) {
+            P t;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) t.v[i] = acc[p][r * PW + i];
+            *reinterpret_cast<P*>(a.P + (((int64_t)cg * a.M + m) * BV + col)) = t;
+          } else {
+#pragma unroll
+            for (int i = 0; i < PW; ++i)
+              if (col + i < a.B) a.F[m * a.ldf + col + i] = acc[p][r * PW + i];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class T>
+__global__ void colgroup_reduce_kernel(const T* __restrict__ P, int CG, int64_t M, int BV, int B, T* __restrict__ F,
+                                       int64_t ldf) {
+  const int64_t total = M * BV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / BV;
+    const int b = (int)(i - m * BV);
+    if (b >= B) continue;
+    T s = T(0);
+    for (int c = 0; c < CG; ++c) s += P[(int64_t)c * total + i];
+    F[m * ldf + b] = s;
+  }
+}
+
+template <class T, int BV, int NP, bool BIN, int WAVES>
+static int launch_col_variant(const ColArgs<T>& a, unsigned grid, size_t lds) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colgroup_kernel<T, BV, NP, BIN, WAVES>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((spmm_colgroup_kernel<T, BV, NP, BIN, WAVES>), dim3(grid), dim3(WAVES * 64), lds, ctx().stream, a);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// Waves per workgroup and row sets per wave (16 rows each).  Rows per workgroup = WAVES * NP * 16 = 2048 (64- and
+// 128-byte tile rows) or 1280 (256-byte rows): NP * ROWB/16 accumulator registers per lane next to the quads in flight,
+// the gathered tile rows and addresses.  16 waves (128 registers each) hide the latencies better (measured, B = 16
+// binary: 0.22 ms vs 0.29 ms with 8 waves) where the accumulators fit.
+constexpr int col_waves(int rowb) { return rowb == 256 ? 8 : 16; }
+constexpr int col_np(int rowb, bool bin = true, int elem = 4) {
+  return rowb == 256 ? ((!bin && elem == 8) ? 8 : 10) : 8;
+}
+constexpr int col_max_rows(int rowb) { return col_waves(rowb) * col_np(rowb) * COL_ROWS; }
+
+// LDS = tile (KC + 1 rows) + two buffers of sub-row bounds of the workgroup's rows (col_max_rows + 1 ints each)
+template <class T>
+int colgroup_chunk_cols(int bv) {
+  const int rowb = bv * (int)sizeof(T);
+  const int64_t bounds = 2 * (((int64_t)(col_max_rows(rowb) + 1) * 4 + 15) / 16 * 16);
+  int64_t kc = ((int64_t)(160 * 1024) - bounds) / rowb - 1;
+  if (kc > 65535) kc = 65535;
+  return (int)kc;
+}
+
+template <class T, int BV, bool BIN>
+struct ColNP {
+  static constexpr int value = col_np(BV * (int)sizeof(T), BIN, (int)sizeof(T));
+};
+
+template <class T>
+int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
+                         DevBuf<T>& partial) {
+  if (W.rows <= 0 || B <= 0) return SS_OK;
+  if (W.align != 4) return fail(SS_EINVAL, "mid-width operand must be quad-aligned");
+  if (B > bv) return fail(SS_EINVAL, "B exceeds the tile width");
+  if (W.SC > colgroup_chunk_cols<T>(bv)) return fail(SS_EINVAL, "chunk does not fit the LDS tile");
+  const int rowb = bv * (int)sizeof(T);
+  if (rowb != 64 && rowb != 128 && rowb != 256) return fail(SS_EINVAL, "tile row must be 64, 128 or 256 bytes");
+  ColArgs<T> a{};
+  a.off = W.off.p; a.idx = W.idx.p; a.val = W.val.p;
+  a.M = W.rows; a.K = W.cols; a.KC = W.SC; a.nchunks = W.nchunks; a.B = B;
+  a.R = R; a.ldr = ldr; a.F = F; a.ldf = ldf;
+  constexpr int PW = 16 / (int)sizeof(T);
+  a.dbg = getenv("SS_COL_DBG") ? atoi(getenv("SS_COL_DBG")) : 0;
+  a.vec_ok = (ldr % PW == 0 && B % PW == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0) ? 1 : 0;
+
+  // the cut: RB row blocks x CG chunk groups.  A workgroup holds 8 waves * NP * 16 rows (accumulators in registers);
+  // RB follows from the row count, CG fills the CUs with one resident round (more chunk groups = more partial sums,
+  // fewer = idle CUs; SS_COL_CG overrides)
+  const int np = col_np(rowb, W.binary, (int)sizeof(T));
+  a.np_used = np;
+  a.rows_per_wg = np * col_waves(rowb) * COL_ROWS;
+  a.RBn = (int)ceil_div(W.rows, (int64_t)a.rows_per_wg);
+  int cgn = ctx().num_cu / a.RBn;
+  if (cgn < 1) cgn = 1;
+  if (cgn > W.nchunks) cgn = W.nchunks;
+  if (cgn > 16) cgn = 16;
+  if (const char* e = getenv("SS_COL_CG")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= W.nchunks) cgn = v;
+  }
+  a.CG = cgn;
+  a.P = nullptr;
+  if (a.CG > 1) {
+    const size_t need = (size_t)a.CG * (size_t)W.rows * (size_t)bv;
+    if (partial.n < need) SS_TRY(partial.alloc(need));
+    a.P = partial.p;
+  }
+  const unsigned grid = (unsigned)(a.RBn * a.CG);
+  if (getenv("SS_COL_DEBUG"))
+    fprintf(stderr, "colgroup: rowb %d KC %d chunks %d RB %d CG %d np %d rows/wg %d grid %u\n", rowb, a.KC, a.nchunks, a.RBn,
+            a.CG, a.np_used, a.rows_per_wg, grid);
+  const size_t lds = (size_t)(W.SC + 1) * rowb + 2 * (((size_t)(a.rows_per_wg + 1) * 4 + 15) / 16 * 16);
+  int rc;
+#define SS_COL(BVV)                                                                                      \
+  (W.binary ? launch_col_variant<T, BVV, ColNP<T, BVV, true>::value, true, col_waves(BVV * (int)sizeof(T))>(a, grid, lds)   \
+            : launch_col_variant<T, BVV, ColNP<T, BVV, false>::value, false, col_waves(BVV * (int)sizeof(T))>(a, grid, lds))
+  if constexpr (sizeof(T) == 4) {
+    switch (bv) {
+      case 16: rc = SS_COL(16); break;
+      case 32: rc = SS_COL(32); break;
+      case 64: rc = SS_COL(64); break;
+      default: return fail(SS_EINVAL, "mid-width tile must be 16, 32 or 64 columns");
+    }
+  } else {
+    switch (bv) {
+      case 8: rc = SS_COL(8); break;
+      case 16: rc = SS_COL(16); break;
+      case 32: rc = SS_COL(32); break;
+      default: return fail(SS_EINVAL, "mid-width tile must be 8, 16 or 32 columns (fp64)");
+    }
+  }
+#undef SS_COL
+  SS_TRY(rc);
+  if (a.CG > 1) {
+    int64_t g = ceil_div(W.rows * bv, 256);
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(colgroup_reduce_kernel<T>, dim3((unsigned)g), dim3(256), 0, ctx().stream, partial.p, a.CG, W.rows,
+                       bv, B, F, ldf);
+    SS_LAUNCH_CHECK();
+  }
+  return SS_OK;
+}
+
+template int colgroup_chunk_cols<float>(int);
+template int colgroup_chunk_cols<double>(int);
+template int launch_spmm_colgroup<float>(const DevChunked<float>&, int, const float*, int64_t, int, float*, int64_t,
+                                         DevBuf<float>&);
+template int launch_spmm_colgroup<double>(const DevChunked<double>&, int, const double*, int64_t, int, double*, int64_t,
+                                          DevBuf<double>&);
+
+}  // namespace ss

@@ -379,6 +379,37 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
         assert_close(ws.spmm(R.astype(dt)), W @ R, dt)
 
 
+@pytest.mark.parametrize("binary", [False, True])
+@pytest.mark.parametrize("dtype,B", [(np.float32, 12), (np.float32, 16), (np.float32, 28), (np.float32, 64), (np.float32, 52),
+                                     (np.float64, 6), (np.float64, 16), (np.float64, 32)])
+def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
+    """Mid width (fp32 9 <= B <= 64, fp64 5 <= B <= 32): the 2-D kernel (spmm_colgroup.hip).  Several row blocks,
+    several chunk groups (partial sums combined in fixed order), several LDS chunks of R per group, sub-rows longer
+    than the prefetched batches (row 7 is full) and empty rows; must agree with scipy and with the row-block / wide
+    kernels, and be bitwise repeatable."""
+    rng = np.random.default_rng(100 + B)
+    M, K = 9011, 2900
+    W = sp.random(M, K, density=0.012, format="lil", random_state=rng, dtype=np.float64)
+    W[7, :] = 1.0
+    W[100:130, :] = 0.0
+    W = W.tocsr()
+    W.data = np.ones(W.nnz) if binary else rng.random(W.nnz) + 0.5
+    W.eliminate_zeros()
+    R = rng.standard_normal((K, B))
+    want = W @ R
+    monkeypatch.setenv("SS_NARROW_CHUNK", "500")     # 6 chunks of R
+    monkeypatch.setenv("SS_COL_FROM", "5")           # also the pattern-only wide cases stay on this kernel
+    for cg in ("1", "3"):
+        monkeypatch.setenv("SS_COL_CG", cg)
+        w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
+        got = w.spmm(R.astype(dtype))
+        assert_close_signed(got, want, dtype)
+        assert np.array_equal(got, w.spmm(R.astype(dtype)))
+    monkeypatch.setenv("SS_COL", "0")
+    monkeypatch.delenv("SS_COL_FROM")
+    assert_close_signed(ss.DeviceSpMat(W.astype(dtype), dtype=dtype).spmm(R.astype(dtype)), want, dtype)
+
+
 @pytest.mark.parametrize("dtype,B", [(np.float32, 16), (np.float32, 24), (np.float32, 50), (np.float64, 12), (np.float64, 32)])
 def test_spmm_mid_width_row_blocks(dtype, B, monkeypatch):
     """8 < B <= 32 (fp64: 16): row-block kernel (spmm_mid.hip) with several rows per lane group and several LDS
