@@ -15,8 +15,10 @@
  *     aborts; ss_last_error() returns a thread-local message for the last failure;
  *   - one process drives one GPU (ss_init(device)); multi-GPU = one process per GPU,
  *     rows/folds sharded by the host layer, RCCL only for the final score gather;
- *   - entry points are serialised by one process-wide lock: calling from several host
- *     threads / Julia tasks is safe, the calls just do not overlap;
+ *   - thread safety: state is handle-scoped.  Calls on DIFFERENT handles may come from several host threads /
+ *     Julia tasks at once and overlap; calls on the same handle queue up on that handle's lock; ss_init /
+ *     ss_shutdown / ss_set_stream / ss_reset_stream exclude everything else while they run.  ss_last_error,
+ *     ss_timing_last and ss_path_last are per host thread;
  *   - `mem` says where caller buffers live: SS_MEM_HOST (copied during the call) or
  *     SS_MEM_DEVICE (used in place, e.g. a torch tensor's data_ptr()); the caller
  *     keeps ownership of every buffer it passes; the library owns what is behind
@@ -78,6 +80,12 @@ int ss_synchronize(void);
  * (stage 2), [3] epilogues/transposes, [4] host->device, [5] device->host,
  * [6] number of SpMM launches, [7] number of stage-1 launches.  Writes min(n,8) values. */
 int ss_timing_last(double* ms, int n);
+/* Which kernels the last predict / spmm call of this host thread went through: a comma-separated list of tags
+ * ("transfer", "transfer_loo", "transfer_dense_bf16_ring", "transfer_dense_bf16_128", "transfer_dense_f32_mfma",
+ * "spmm_sell", "spmm_sell_sorted", "spmm_colgroup", "spmm_rowblock", "spmm_chunked_narrow", ...), NUL-terminated, truncated
+ * to n - 1 characters.  Lets a caller (and the parity tests) assert that a size-dependent routing decision was the one
+ * expected.  Has no counterpart in the reference (its only switch is GPU::Bool, src/core.jl:402,404). */
+int ss_path_last(char* buf, int n);
 /* enable != 0: from now on the timings of successive calls add up (ss_timing_last returns the sums and launch
  * counts since the hold began) instead of replacing one another, so that a benchmark loop need not stop after
  * every call to read them; enable == 0: back to per-call timings. */

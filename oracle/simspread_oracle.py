@@ -322,6 +322,37 @@ def predict_loo_factored(X, Y, clean_flag: bool = False, queries: Iterable[int] 
     return out
 
 
+def predict_loo_dense(X, Y, clean_flag: bool = False, queries: Iterable[int] | None = None) -> np.ndarray:
+    """The same leave-one-out identity as predict_loo_factored for a DENSE featurized similarity ``X`` (a numpy
+    array, e.g. cutoff(S, alpha, weighted) of the dense-similarity regime, 90 % full): plain dense mat-vecs, no
+    sparse conversion of X.  ``Y`` stays sparse.  tests/test_oracle.py checks it against predict_loo_factored."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = sp.csr_matrix(Y, dtype=np.float64)
+    Y.eliminate_zeros()
+    n = X.shape[0]
+    assert X.shape == (n, n)
+    nzX = X != 0
+    kf = nzX.sum(axis=0).astype(np.float64)
+    ks = nzX.sum(axis=1).astype(np.float64) + np.asarray((Y != 0).sum(axis=1)).ravel()
+    kt = np.asarray((Y != 0).sum(axis=0)).ravel().astype(np.float64)
+    qs = list(range(n)) if queries is None else list(queries)
+    out = np.zeros((len(qs), Y.shape[1]))
+    YT = Y.T.tocsr()
+    for o, i in enumerate(qs):
+        u = X[i] * _inv_count(kf - nzX[i])     # the query leaves every feature column it touched (src/core.jl:153)
+        u[i] = 0.0                             # its own feature column is dropped (src/core.jl:152)
+        v = X @ u
+        z = v * _inv_count(ks - nzX[:, i])     # feature column f_i is gone from every source row
+        z[i] = 0.0
+        row = YT @ z
+        if clean_flag:
+            yi = np.zeros(Y.shape[1])
+            yi[Y.indices[Y.indptr[i]:Y.indptr[i + 1]]] = 1.0
+            row = np.where((kt - yi) == 0, -99.0, row)
+        out[o] = row
+    return out
+
+
 # --------------------------------------------------------------------------- synthetic inputs shared by tests / bench
 def synth_bipartite(nq: int, ns: int, nf: int, nt: int, dx: float, dy: float, seed: int,
                     weighted: bool = True, alpha: float = 0.5, dtype=np.float32):

@@ -48,6 +48,7 @@ def _sigs():
         "ss_synchronize": ([], _int),
         "ss_timing_last": ([_vp, _int], _int),
         "ss_timing_hold": ([_int], _int),
+        "ss_path_last": ([_vp, _int], _int),
         "ss_graph_destroy": ([_vp], _int),
         "ss_graph_info": ([_vp, _vp], _int),
         "ss_graph_degrees": ([_vp, _vp, _vp, _vp], _int),
@@ -144,3 +145,10 @@ def timing_last():
     check(lib().ss_timing_last(buf.ctypes.data, 8))
     return dict(total_ms=buf[0], transfer_ms=buf[1], spmm_ms=buf[2], epilogue_ms=buf[3], h2d_ms=buf[4],
                 d2h_ms=buf[5], spmm_launches=int(buf[6]), transfer_launches=int(buf[7]))
+
+
+def path_last() -> list:
+    """Kernel tags the last predict / spmm call of this thread went through (ss_path_last)."""
+    buf = C.create_string_buffer(512)
+    check(lib().ss_path_last(C.cast(buf, C.c_void_p), 512))
+    return [t for t in buf.value.decode().split(",") if t]

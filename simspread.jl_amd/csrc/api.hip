@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <type_traits>
 
 #include "graph.hpp"
@@ -36,8 +37,32 @@ int require_init() {
   return SS_OK;
 }
 
+Timing& timing() {
+  static thread_local Timing t;
+  if (t.generation != ctx().generation) {  // the context these events belonged to is gone
+    t.pool.clear();
+    t.spans.clear();
+    t.used = 0;
+    t.hold = false;
+    t.generation = ctx().generation;
+  }
+  return t;
+}
+
+std::string& path_note() {
+  static thread_local std::string s;
+  return s;
+}
+void path_add(const char* tag) {
+  std::string& s = path_note();
+  if (s.find(tag) != std::string::npos) return;
+  if (!s.empty()) s += ",";
+  s += tag;
+}
+
 void timing_begin_call() {
-  Timing& t = ctx().timing;
+  Timing& t = timing();
+  if (!t.hold) path_note().clear();
   t.dirty = true;
   if (t.hold) return;  // accumulate: the spans of this call join those already recorded
   t.used = 0;
@@ -47,7 +72,7 @@ void timing_begin_call() {
 }
 
 int timing_mark(hipEvent_t* ev) {
-  Timing& t = ctx().timing;
+  Timing& t = timing();
   if (t.used == t.pool.size()) {
     hipEvent_t e;
     SS_HIP(hipEventCreate(&e));
@@ -58,8 +83,8 @@ int timing_mark(hipEvent_t* ev) {
   return SS_OK;
 }
 
-void timing_span(int stage, hipEvent_t a, hipEvent_t b) { ctx().timing.spans.push_back({stage, a, b}); }
-void timing_count(int stage, double inc) { ctx().timing.extra[stage] += inc; }
+void timing_span(int stage, hipEvent_t a, hipEvent_t b) { timing().spans.push_back({stage, a, b}); }
+void timing_count(int stage, double inc) { timing().extra[stage] += inc; }
 
 static int check_mem(int mem) {
   if (mem != SS_MEM_HOST && mem != SS_MEM_DEVICE) return fail(SS_EINVAL, "mem must be SS_MEM_HOST or SS_MEM_DEVICE");
@@ -169,14 +194,19 @@ static int spread_impl(const T* G, int64_t rows, int64_t cols, int64_t ld, T* W,
 }
 
 // ------------------------------------------------------------------ graph handles
-template <class T>
-struct GraphBox {
+// Every handle starts with its precision tag and its own lock: an entry point holds the handle's lock while it
+// works on it (operands are cut lazily, workspaces live in the handle), so calls on DIFFERENT handles overlap
+// and calls on the same handle queue up.
+struct HandleHead {
   int dtype;  // 4 or 8 = sizeof(T), guards against mixing _f32/_f64 entry points
+  std::mutex mu;
+};
+template <class T>
+struct GraphBox : HandleHead {
   Graph<T> g;
 };
 template <class T>
-struct SpMatBox {
-  int dtype;
+struct SpMatBox : HandleHead {
   SpMat<T> m;
 };
 
@@ -894,13 +924,28 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
 // ==================================================================== extern "C"
 using namespace ss;
 
-// The library keeps one context per process (device, stream, timing of the last call).  Entry points that
-// touch it are serialised, so calls from several host threads / Julia tasks are safe (they do not overlap).
-static std::recursive_mutex& api_mutex() {
-  static std::recursive_mutex m;
+// Locking.  The process-wide context (device, stream) is read by every entry point and changed only by ss_init /
+// ss_shutdown / ss_set_stream / ss_reset_stream: those take the context lock exclusively, everything else shares it.
+// Work on a handle additionally holds that handle's own lock (HandleHead::mu).  Timings, the kernel-path note and
+// the error message are per host thread.  So calls from several host threads / Julia tasks on different handles
+// run concurrently (their kernels interleave on the library stream), calls on one handle are serialised.
+static std::shared_mutex& ctx_mutex() {
+  static std::shared_mutex m;
   return m;
 }
-#define SS_API_LOCK() std::lock_guard<std::recursive_mutex> _ss_api_guard(api_mutex())
+// HIP's current device is per host thread: a thread that never called ss_init still has to launch on the library's
+static inline void bind_device() {
+  if (ctx().inited) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx().device) (void)hipSetDevice(ctx().device);
+  }
+}
+#define SS_API_EXCLUSIVE() std::unique_lock<std::shared_mutex> _ss_ctx_guard(ctx_mutex())
+#define SS_API_LOCK()                                             \
+  std::shared_lock<std::shared_mutex> _ss_ctx_guard(ctx_mutex()); \
+  bind_device()
+#define SS_HANDLE_LOCK(h) \
+  std::unique_lock<std::mutex> _ss_handle_guard(reinterpret_cast<HandleHead*>(const_cast<void*>(static_cast<const void*>(h)))->mu)
 
 template <class T>
 static int jaccard_impl(const T* F, int64_t n, int64_t d, int64_t ld, T* S, int64_t lds_, int mem) {
@@ -924,6 +969,8 @@ static int jaccard_impl(const T* F, int64_t n, int64_t d, int64_t ld, T* S, int6
 
 extern "C" {
 
+static int shutdown_locked();
+
 int ss_version(void) { return SS_VERSION; }
 
 const char* ss_last_error(void) { return last_error().c_str(); }
@@ -935,14 +982,14 @@ int ss_device_count(void) {
 }
 
 int ss_init(int device) {
-  SS_API_LOCK();
+  SS_API_EXCLUSIVE();
   Ctx& c = ctx();
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) return fail(SS_ENODEV, "no HIP device visible (%s)", hipGetErrorString(e));
   if (device < 0 || device >= n) return fail(SS_EINVAL, "device %d outside 0..%d", device, n - 1);
   if (c.inited && c.device == device) return SS_OK;
-  if (c.inited) ss_shutdown();
+  if (c.inited) shutdown_locked();
   SS_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   SS_HIP(hipGetDeviceProperties(&prop, device));
@@ -956,15 +1003,17 @@ int ss_init(int device) {
   return SS_OK;
 }
 
-int ss_shutdown(void) {
-  SS_API_LOCK();
+static int shutdown_locked() {
   Ctx& c = ctx();
   if (!c.inited) return SS_OK;
   (void)hipStreamSynchronize(c.stream);
-  for (hipEvent_t e : c.timing.pool) (void)hipEventDestroy(e);
-  c.timing.pool.clear();
-  c.timing.spans.clear();
-  c.timing.used = 0;
+  Timing& t = timing();
+  for (hipEvent_t e : t.pool) (void)hipEventDestroy(e);
+  t.pool.clear();
+  t.spans.clear();
+  t.used = 0;
+  ++c.generation;  // other threads drop their (now stale) event lists at their next call
+  t.generation = c.generation;
   (void)hipStreamDestroy(c.own_stream);
   c.own_stream = nullptr;
   c.stream = nullptr;
@@ -973,8 +1022,13 @@ int ss_shutdown(void) {
   return SS_OK;
 }
 
+int ss_shutdown(void) {
+  SS_API_EXCLUSIVE();
+  return shutdown_locked();
+}
+
 int ss_set_stream(void* hip_stream) {
-  SS_API_LOCK();
+  SS_API_EXCLUSIVE();
   SS_TRY(require_init());
   Ctx& c = ctx();
   SS_HIP(hipStreamSynchronize(c.stream));
@@ -983,7 +1037,7 @@ int ss_set_stream(void* hip_stream) {
 }
 
 int ss_reset_stream(void) {
-  SS_API_LOCK();
+  SS_API_EXCLUSIVE();
   SS_TRY(require_init());
   Ctx& c = ctx();
   SS_HIP(hipStreamSynchronize(c.stream));
@@ -998,10 +1052,19 @@ int ss_synchronize(void) {
   return SS_OK;
 }
 
+int ss_path_last(char* buf, int n) {
+  if (!buf || n <= 0) return fail(SS_EINVAL, "ss_path_last: no buffer");
+  const std::string& s = path_note();
+  const size_t m = s.size() < (size_t)(n - 1) ? s.size() : (size_t)(n - 1);
+  memcpy(buf, s.data(), m);
+  buf[m] = 0;
+  return SS_OK;
+}
+
 int ss_timing_hold(int enable) {
   SS_API_LOCK();
   SS_TRY(require_init());
-  Timing& t = ctx().timing;
+  Timing& t = timing();
   t.hold = false;
   if (enable) {
     timing_begin_call();  // start from zero
@@ -1014,7 +1077,7 @@ int ss_timing_last(double* ms, int n) {
   SS_API_LOCK();
   SS_TRY(require_init());
   if (!ms || n <= 0) return fail(SS_EINVAL, "ss_timing_last: bad buffer");
-  Timing& t = ctx().timing;
+  Timing& t = timing();
   if (t.dirty) {
     SS_HIP(hipStreamSynchronize(ctx().stream));
     for (double& r : t.resolved) r = 0;
@@ -1126,8 +1189,12 @@ int ss_graph_create_similarity_f32(int64_t nq, int64_t ns, int64_t nt, const flo
 int ss_graph_destroy(ss_graph* h) {
   SS_API_LOCK();
   if (!h) return SS_OK;
-  if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   const int dtype = *reinterpret_cast<int*>(h);
+  if (dtype != 4 && dtype != 8) return fail(SS_EINVAL, "not a graph handle");
+  {  // wait for a call that still works on the handle (the caller must not start new ones), then for the device
+    SS_HANDLE_LOCK(h);
+    if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
+  }
   if (dtype == 4) delete reinterpret_cast<GraphBox<float>*>(h);
   else if (dtype == 8) delete reinterpret_cast<GraphBox<double>*>(h);
   else return fail(SS_EINVAL, "not a graph handle");
@@ -1136,6 +1203,8 @@ int ss_graph_destroy(ss_graph* h) {
 
 int ss_graph_info(const ss_graph* h, int64_t sizes[7]) {
   SS_API_LOCK();
+  if (!h) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(h);
   if (!h || !sizes) return fail(SS_EINVAL, "NULL argument");
   const int dtype = *reinterpret_cast<const int*>(h);
   auto fill = [&](auto* b) {
@@ -1150,6 +1219,8 @@ int ss_graph_info(const ss_graph* h, int64_t sizes[7]) {
 
 int ss_graph_degrees(const ss_graph* h, int64_t* kf, int64_t* ks, int64_t* kt) {
   SS_API_LOCK();
+  if (!h) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(h);
   SS_TRY(require_init());
   if (!h) return fail(SS_EINVAL, "graph handle is NULL");
   const int dtype = *reinterpret_cast<const int*>(h);
@@ -1175,34 +1246,46 @@ int ss_graph_degrees(const ss_graph* h, int64_t* kf, int64_t* ks, int64_t* kt) {
 int ss_predict_f32(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean, float* out, int64_t ld,
                    int layout, int mem) {
   SS_API_LOCK();
+  if (!g) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(g);
   if (rows_kind != SS_ROWS_QUERY && rows_kind != SS_ROWS_SOURCE) return fail(SS_EINVAL, "bad rows_kind");
   return predict_impl<float>(g, rows_kind, row_begin, row_end, clean, out, ld, layout, mem);
 }
 int ss_predict_f64(ss_graph* g, int rows_kind, int64_t row_begin, int64_t row_end, int clean, double* out, int64_t ld,
                    int layout, int mem) {
   SS_API_LOCK();
+  if (!g) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(g);
   if (rows_kind != SS_ROWS_QUERY && rows_kind != SS_ROWS_SOURCE) return fail(SS_EINVAL, "bad rows_kind");
   return predict_impl<double>(g, rows_kind, row_begin, row_end, clean, out, ld, layout, mem);
 }
 int ss_predict_loo_f32(ss_graph* g, int64_t i_begin, int64_t i_end, int clean, float* out, int64_t ld, int layout,
                        int mem) {
   SS_API_LOCK();
+  if (!g) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(g);
   return predict_impl<float>(g, 2, i_begin, i_end, clean, out, ld, layout, mem);
 }
 int ss_predict_loo_f64(ss_graph* g, int64_t i_begin, int64_t i_end, int clean, double* out, int64_t ld, int layout,
                        int mem) {
   SS_API_LOCK();
+  if (!g) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(g);
   return predict_impl<double>(g, 2, i_begin, i_end, clean, out, ld, layout, mem);
 }
 
 int ss_predict_kfold_f32(ss_graph* g, const int32_t* fold_of_source, int nfolds, int clean, float* out, int64_t ld,
                          int layout, int mem) {
   SS_API_LOCK();
+  if (!g) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(g);
   return predict_kfold_impl<float>(g, fold_of_source, nfolds, clean, out, ld, layout, mem);
 }
 int ss_predict_kfold_f64(ss_graph* g, const int32_t* fold_of_source, int nfolds, int clean, double* out, int64_t ld,
                          int layout, int mem) {
   SS_API_LOCK();
+  if (!g) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(g);
   return predict_kfold_impl<double>(g, fold_of_source, nfolds, clean, out, ld, layout, mem);
 }
 
@@ -1261,8 +1344,12 @@ int ss_spmat_create_csr_f64(int64_t rows, int64_t cols, const int64_t* ptr, cons
 int ss_spmat_destroy(ss_spmat* h) {
   SS_API_LOCK();
   if (!h) return SS_OK;
-  if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   const int dtype = *reinterpret_cast<int*>(h);
+  if (dtype != 4 && dtype != 8) return fail(SS_EINVAL, "not a matrix handle");
+  {  // wait for a call that still works on the handle (the caller must not start new ones), then for the device
+    SS_HANDLE_LOCK(h);
+    if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
+  }
   if (dtype == 4) delete reinterpret_cast<SpMatBox<float>*>(h);
   else if (dtype == 8) delete reinterpret_cast<SpMatBox<double>*>(h);
   else return fail(SS_EINVAL, "not a matrix handle");
@@ -1271,15 +1358,21 @@ int ss_spmat_destroy(ss_spmat* h) {
 int ss_spmm_f32(ss_spmat* w, const float* R, int64_t B, int64_t ldr, int r_layout, float* F, int64_t ldf, int f_layout,
                 int mem) {
   SS_API_LOCK();
+  if (!w) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(w);
   return spmm_impl<float>(w, R, B, ldr, r_layout, F, ldf, f_layout, mem);
 }
 int ss_spmm_f64(ss_spmat* w, const double* R, int64_t B, int64_t ldr, int r_layout, double* F, int64_t ldf,
                 int f_layout, int mem) {
   SS_API_LOCK();
+  if (!w) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(w);
   return spmm_impl<double>(w, R, B, ldr, r_layout, F, ldf, f_layout, mem);
 }
 int ss_spmat_cost(const ss_spmat* h, int64_t B, double* bytes, double* flops) {
   SS_API_LOCK();
+  if (!h) return fail(SS_EINVAL, "handle is NULL");
+  SS_HANDLE_LOCK(h);
   if (!h) return fail(SS_EINVAL, "matrix handle is NULL");
   const int dtype = *reinterpret_cast<const int*>(h);
   int64_t rows, cols, nnz;

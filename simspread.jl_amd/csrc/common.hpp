@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ struct Timing {
   double resolved[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool dirty = false;
   bool hold = false;  // ss_timing_hold: calls accumulate instead of replacing one another
+  unsigned generation = 0;
 };
 
 struct Ctx {
@@ -54,9 +56,14 @@ struct Ctx {
   hipStream_t own_stream = nullptr;  // created by ss_init; `stream` may point at a caller's stream instead
   int num_cu = 256;
   size_t lds_per_block = 160 * 1024;
-  Timing timing;
+  unsigned generation = 0;           // bumped by ss_shutdown: events created before belong to a dead context
 };
 Ctx& ctx();
+// Timings and the kernel-path note of the last call are per host thread (like ss_last_error): calls from
+// several threads on different handles overlap and must not share event lists.
+Timing& timing();
+std::string& path_note();            // kernels the last predict / spmm call of this thread went through
+void path_add(const char* tag);
 int require_init();
 
 // stage ids for Timing::Span / ss_timing_last

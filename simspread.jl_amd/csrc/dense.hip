@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(256) transfer_dense_kernel(DenseArgs a) {
 int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
                           int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows) {
   if (nrows <= 0 || d.ns <= 0) return SS_OK;
+  path_add("transfer_dense_f32_mfma");
   DenseArgs a{};
   if (loo || source_rows) { a.A = d.Ss.p + row_begin; a.lda = d.ns; }  // rows of the source similarity itself
   else { a.A = d.Sq.p + row_begin; a.lda = d.nq; }

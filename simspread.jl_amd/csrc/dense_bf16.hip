@@ -352,7 +352,7 @@ static int launch_ring(DenseBf16Args& a, int64_t Mp, int64_t Np) {
     a.bidx[p] = nbs - 1;
   }
   a.nbs = nbs;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_dense_bf16_ring_kernel<LOO, TN, BK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -441,8 +441,11 @@ int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k,
   // 128 x 128 kernel with two workgroups per CU 65).  SS_DENSE_RING=0 / 1 forces the choice.
   const bool ring_ok = (Mp / RING_TM) * (Np / 256) >= ctx().num_cu;
   const char* ring_env = getenv("SS_DENSE_RING");  // 0: never, 1: always, unset: by size
-  if (ring_env ? atoi(ring_env) != 0 : ring_ok)
+  if (ring_env ? atoi(ring_env) != 0 : ring_ok) {
+    path_add("transfer_dense_bf16_ring");
     return loo ? launch_ring<true, 256, 64>(a, Mp, Np) : launch_ring<false, 256, 64>(a, Mp, Np);
+  }
+  path_add("transfer_dense_bf16_128");
   a.gy = (int)(Mp / BT);
   dim3 grid((unsigned)(a.gx * a.gy));
   if (loo) hipLaunchKernelGGL(transfer_dense_bf16_kernel<true>, grid, dim3(256), 0, ctx().stream, a);

@@ -395,6 +395,7 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
   bool binm = true;
   for (int t = 0; t < nterms; ++t) binm = binm && Mt[t]->binary;
   const bool dual = transfer_dual();
+  path_add("transfer");
   const size_t lds = (size_t)(p.SC + 64) * sizeof(T) * (dual ? 2 : 1);
   SS_TRY((launch_transfer_variant<T, false>(p, (unsigned)grid, lds, binm, dual)));
   return SS_OK;
@@ -419,6 +420,7 @@ int launch_transfer_loo(const DevCsr<T>& X, const DevChunked<T>& XT, const int* 
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
   const bool dual = transfer_dual();
+  path_add("transfer_loo");
   const size_t lds = (size_t)(p.SC + 64) * sizeof(T) * (dual ? 2 : 1) + (size_t)((p.SC + 31) / 32) * 4;
   SS_TRY((launch_transfer_variant<T, true>(p, (unsigned)grid, lds, XT.binary, dual)));
   return SS_OK;
@@ -600,6 +602,7 @@ template <class T>
 int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T* F, int64_t ldf,
                      const int* clean_deg, const int* out_rows) {
   if (B <= 0 || W.rows <= 0) return SS_OK;
+  path_add(W.sorted ? "spmm_sell_sorted" : "spmm_sell");
   constexpr int QT = sizeof(T) == 4 ? 4 : 2;
   SellArgs<T> a{};
   a.off = W.off.p;
@@ -626,7 +629,7 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
     if (gy > maxy) gy = maxy > 0 ? maxy : 1;
   }
   const dim3 grid(gx, gy);
-  static bool attr_set[2] = {false, false};
+  static std::atomic<bool> attr_set[2] = {{false}, {false}};
   if (W.binary) {
     if (!attr_set[0]) {
       SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, true>),
@@ -702,6 +705,7 @@ template <class T>
 int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf) {
   if (W.rows <= 0 || B <= 0) return SS_OK;
   if (B > 64) return fail(SS_EINVAL, "narrow SpMM serves B <= 64 (got %d)", B);
+  path_add("spmm_csr_narrow");
   const int block = 256;
   const int grid = grid_1d(W.rows * 64, block, 256 * 32);
 #define SS_NARROW(VEC, LPN)                                                                          \
@@ -951,7 +955,7 @@ int narrow_chunk_cols(int bv) {
 
 template <class T, int VEC, int LPN, int GL, int UR>
 static int launch_narrow_variant(const NarrowArgs<T>& a, unsigned grid, size_t lds) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -986,6 +990,7 @@ int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64
                                DevBuf<T>& partial) {
   if (W.rows <= 0 || B <= 0) return SS_OK;
   if (W.align != 4) return fail(SS_EINVAL, "narrow operand must be quad-aligned");
+  path_add("spmm_chunked_narrow");
   NarrowArgs<T> a{};
   a.off = W.off.p; a.idx = W.idx.p; a.val = W.val.p;
   a.M = W.rows; a.K = W.cols; a.KC = W.SC; a.nchunks = W.nchunks; a.B = B;
@@ -1102,6 +1107,7 @@ __global__ void __launch_bounds__(RA_THREADS) spmm_regacc_kernel(RegAccArgs a) {
 int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf) {
   if (W.rows <= 0 || B <= 0) return SS_OK;
   if (B > 64 || W.row_bytes != 256) return fail(SS_EINVAL, "register-accumulator SpMM serves B <= 64");
+  path_add("spmm_regacc");
   RegAccArgs a{};
   a.off = W.off.p; a.ent = W.ent.p; a.M = W.rows; a.K = W.cols; a.KC = W.KC; a.nchunks = W.nchunks; a.B = B;
   a.R = R; a.ldr = ldr; a.F = F; a.ldf = ldf;
@@ -1111,7 +1117,7 @@ int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, fl
   if (rpw < 1) rpw = 1;
   a.rpw = (int)rpw;
   const unsigned grid = (unsigned)ceil_div(W.rows, rpw * nw);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_regacc_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -326,7 +326,7 @@ __global__ void colgroup_reduce_kernel(const T* __restrict__ P, int CG, int64_t 
 
 template <class T, int BV, int NP, bool BIN, int WAVES>
 static int launch_col_variant(const ColArgs<T>& a, unsigned grid, size_t lds) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_colgroup_kernel<T, BV, NP, BIN, WAVES>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -367,6 +367,7 @@ int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr
                          DevBuf<T>& partial) {
   if (W.rows <= 0 || B <= 0) return SS_OK;
   if (W.align != 4) return fail(SS_EINVAL, "mid-width operand must be quad-aligned");
+  path_add("spmm_colgroup");
   if (B > bv) return fail(SS_EINVAL, "B exceeds the tile width");
   if (W.SC > colgroup_chunk_cols<T>(bv)) return fail(SS_EINVAL, "chunk does not fit the LDS tile");
   const int rowb = bv * (int)sizeof(T);

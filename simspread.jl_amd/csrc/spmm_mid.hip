@@ -203,7 +203,7 @@ static int launch_mid_variant(MidArgs<T>& a, size_t lds) {
   if (rpw < 1) rpw = 1;
   a.rows_per_wg = (int)rpw;
   const unsigned grid = (unsigned)ceil_div(a.M, rpw);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_rowblock_kernel<T, BV, GL, UR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -230,6 +230,7 @@ template <class T>
 int launch_spmm_rowblock(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf) {
   if (W.rows <= 0 || B <= 0) return SS_OK;
   if (W.align != 4) return fail(SS_EINVAL, "mid-width operand must be quad-aligned");
+  path_add("spmm_rowblock");
   if (B > bv) return fail(SS_EINVAL, "B exceeds the tile width");
   if (W.SC > mid_chunk_cols<T>(bv)) return fail(SS_EINVAL, "chunk does not fit the LDS tile");
   MidArgs<T> a{};

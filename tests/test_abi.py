@@ -43,3 +43,41 @@ def test_product_never_imports_the_oracle():
                 with open(os.path.join(dirpath, f)) as fh:
                     text = fh.read()
                 assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_entry_points_are_safe_from_several_threads_without_a_device():
+    """Handle-scoped state, per-thread error messages: several host threads hammering entry points that must fail
+    (no device initialised here) get their own message each and nothing crashes or deadlocks.  The two-handles-in-
+    two-threads run on a real device is tests/test_gpu_parity.py::test_two_threads_two_handles."""
+    import ctypes as C
+    import threading
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the GPU test")
+    lib = _lib.load()
+    errors, msgs = [], {}
+
+    def worker(tid):
+        try:
+            for i in range(200):
+                if tid % 2 == 0:
+                    rc = lib.ss_synchronize()
+                    want = "ss_init"
+                else:
+                    rc = lib.ss_path_last(None, 0)
+                    want = "ss_path_last"
+                msg = lib.ss_last_error().decode()
+                if rc == 0 or want not in msg:
+                    errors.append((tid, i, rc, msg))
+            msgs[tid] = msg
+        except Exception as e:  # pragma: no cover
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in threads), "deadlock"
+    assert not errors, errors[:3]
+    assert "ss_init" in msgs[0] and "ss_path_last" in msgs[1]

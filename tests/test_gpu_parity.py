@@ -198,6 +198,61 @@ def test_results_are_bitwise_reproducible():
     assert np.array_equal(g2.predict("source"), s)
 
 
+def test_stage1_bank_schedule_changes_no_bit(monkeypatch):
+    """The stage-1 operand orders the entries of every sub-row by LDS bank (chunk_fill_kernel); every accumulator still
+    receives the same addends in the same order, so scores must be bit-identical with and without it."""
+    Xq, Xs, Ys = O.synth_bipartite(257, 3000, 3000, 700, 0.05, 0.02, seed=33, dtype=np.float32)
+    monkeypatch.setenv("SS_CHUNK_SCHED", "0")
+    g0 = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    a, sa = g0.predict("query").copy(), g0.predict("source").copy()
+    monkeypatch.setenv("SS_CHUNK_SCHED", "1")
+    g1 = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    assert np.array_equal(g1.predict("query"), a)
+    assert np.array_equal(g1.predict("source"), sa)
+    monkeypatch.setenv("SS_TRANSFER_CHUNK", "96")      # sub-rows of a few entries: mostly below the 32-entry threshold
+    g2 = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    want = O.predict_factored(Xq.astype(np.float64), Xs.astype(np.float64), Ys.astype(np.float64), "query")
+    assert np.abs(g2.predict("query") - want).max() / np.abs(want).max() < 1e-5
+
+
+def test_two_threads_two_handles():
+    """Handle-scoped locking: two host threads, each predicting on its own handle at the same time (their kernels
+    interleave on the library stream), must produce exactly what the same calls give one after the other."""
+    import threading
+    graphs, want = [], []
+    for seed in (41, 42):
+        Xq, Xs, Ys = O.synth_bipartite(400, 1500, 1500, 600, 0.05, 0.02, seed=seed, dtype=np.float32)
+        g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+        graphs.append(g)
+        want.append((g.predict("query").copy(), g.predict("source").copy()))
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(20):
+                q = graphs[i].predict("query")
+                s = graphs[i].predict("source")
+                if not (np.array_equal(q, want[i][0]) and np.array_equal(s, want[i][1])):
+                    errors.append((i, "mismatch"))
+        except Exception as e:
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "deadlock"
+    assert not errors, errors[:3]
+    # the same handle from two threads: calls queue up on the handle's lock, results still exact
+    threads = [threading.Thread(target=worker, args=(0,)) for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors[:3]
+
+
 def test_multi_chunk_and_row_batches(monkeypatch):
     # force several LDS chunks of W's columns and several transfer batches; results must not change
     Xq, Xs, Ys = O.synth_bipartite(150, 700, 700, 300, 0.05, 0.03, seed=9, dtype=np.float32)

@@ -197,3 +197,36 @@ def test_name_check_needs_equal_counts():
     y = Named(np.ones((3, 1)), ["a", "b", "c"], ["t"])
     with pytest.raises(ValueError, match="DimensionMismatch"):
         O.construct_single(y, X)
+
+
+def test_loo_dense_form_equals_factored_form():
+    """predict_loo_dense (used to check the dense-similarity regime at sizes where a sparse copy of a 90 % full
+    matrix is impractical) against predict_loo_factored, weighted and unweighted, with an isolated target."""
+    rng = np.random.default_rng(5)
+    n, nt = 60, 17
+    S = rng.random((n, n)); S = np.triu(S, 1); S = S + S.T; np.fill_diagonal(S, 1.0)
+    Y = (rng.random((n, nt)) < 0.15).astype(np.float64)
+    Y[:, 3] = 0.0
+    Y[5, 4] = 1.0; Y[:5, 4] = 0.0; Y[6:, 4] = 0.0          # a target whose only edge belongs to one query
+    for alpha, weighted in ((0.1, True), (0.5, False), (0.9, True)):
+        X = O.cutoff(S, alpha, weighted)
+        a = O.predict_loo_dense(X, Y, clean_flag=True)
+        b = O.predict_loo_factored(X, Y, clean_flag=True)
+        assert np.abs(a - b).max() < 1e-13
+        assert ((a == -99) == (b == -99)).all()
+
+
+def test_c_oracle_equals_python_oracle():
+    """oracle/factored.c (the checker of the full-size GPU tests and bench.py's cpu_baseline) against the numpy
+    factored form it restates, on a seeded graph with a zero-degree feature, an isolated source and weighted edges."""
+    from oracle import c_oracle
+    Xq, Xs, Ys = O.synth_bipartite(70, 90, 90, 41, 0.08, 0.06, seed=11, weighted=True, dtype=np.float64)
+    Xs = Xs.tolil(); Xs[:, 7] = 0.0; Xs[12, :] = 0.0; Xs = Xs.tocsr(); Xs.eliminate_zeros()
+    Ys = Ys.tolil(); Ys[12, :] = 0.0; Ys = Ys.tocsr(); Ys.eliminate_zeros()
+    want = O.predict_factored(Xq, Xs, Ys, "query")
+    got = c_oracle.predict_query(Xq, Xs, Ys)
+    assert np.abs(got - want).max() <= 1e-15 * max(1.0, np.abs(want).max()) * 64
+    prep = c_oracle.Prepared(Xq, Xs, Ys)
+    assert np.array_equal(prep.predict(3, 40), got[3:40])       # prepared form == one-shot form, any row block
+    assert np.array_equal(prep.predict(threads=1), got)
+    prep.close()
