@@ -7,7 +7,15 @@ synthetic input that is already resident in HBM: BASELINE.json configs[1]
 Multi-GPU (torch.distributed, one rank per GPU): query rows are independent, so every rank scores its
 own 10k-query shard against the replicated source/target graph (weak scaling, no data-path collective).
 
-Prints ONE JSON line on rank 0 (driver contract) with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 (driver contract).  Besides the headline it carries
+    roofline        the time-dominant kernel of the step (stage 1, transfer_kernel) against the HBM roofline on
+                    algorithmic bytes, with what actually limits it
+    roofline_spmm   the W*R SpMM of the step (stage 2, B = 10^4 columns): fp32 FMA rate and HBM fraction
+    spmm_narrow_sweep  the W*R SpMM at the north-star size (100k x 100k, 1 %) for B = 1 .. 64: HBM fractions
+    c3_loo          BASELINE configs[2] (100k x 100k, 1 %, leave-one-out) fold throughput of THIS run's ranks,
+                    without and with the final score gather -- the curve the north star asks for
+    cpu_baseline    the reference algorithm on the host cores: the factored C/OpenMP port on the full workload
+                    and the literal dense A*(W*W) (numpy / OpenBLAS dgemm, what SimSpread.jl executes) down-scaled
 """
 import argparse
 import json
@@ -46,32 +54,24 @@ def synth_c2(nq, ns, nf, nt, dx, dy, seed, rank, weighted=True):
     return Xq, Xs, Ys
 
 
-def pmc_field(kernel_substr, field):
+def pmc_entry(kernel_substr):
+    """Counters of a kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, tools/profile.sh).  bench.py cannot run the profiler on itself, so
+    these are the figures of the profiled run of the same command; they are only handed on when the kernel
+    sources are the ones that were profiled (source hash recorded with the profile), otherwise null."""
     try:
+        from simspread_jl_amd import _lib
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             d = json.load(f)
+        if d.get("source_sha") != _lib.source_hash():
+            return None, "profiles/pmc_latest.json was taken from other kernel sources (sha %s, running %s): dropped" % (
+                d.get("source_sha"), _lib.source_hash())
         for k, v in d["kernels"].items():
             if kernel_substr in k:
-                return v.get(field)
-    except Exception:
-        pass
-    return None
-
-
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for wide coalesced reads on gfx950).  bench.py cannot run the profiler on itself, so this
-    is the figure measured for the same command when the profile was taken; null if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            d = json.load(f)
-        for k, v in d["kernels"].items():
-            if kernel_substr in k:
-                return v["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+                return v, "profiles/pmc_latest.json@%s" % d.get("source_sha")
+    except Exception as e:  # missing / unreadable profile: no traffic figure
+        return None, "no profile (%s)" % type(e).__name__
+    return None, "kernel not in profiles/pmc_latest.json"
 
 
 def csr_bytes(nnz, rows, vb=4):
@@ -80,7 +80,8 @@ def csr_bytes(nnz, rows, vb=4):
 
 def spmm_sweep(ss, torch, steps=5):
     """Narrow-R regime of the W*R SpMM at the north-star size: W 100k x 100k, 1 % (nnz ~1e8), fp32,
-    B in {1,4,8,16,32,64}; HBM roofline fraction on algorithmic bytes."""
+    B in {1,4,8,16,32,64}; HBM roofline fraction on algorithmic bytes (CSR at 8 B/nnz) and on the
+    bytes the kernels really stream (chunk-major operand: 2-byte local index + 4-byte value = 6 B/nnz)."""
     import ctypes as C
     from simspread_jl_amd import _lib as L
     M = K = 100_000
@@ -118,15 +119,18 @@ def spmm_sweep(ss, torch, steps=5):
                 ms.append(tl["spmm_ms"] + tl["epilogue_ms"])  # layout transposes of the wide path count too
         t = float(np.mean(ms)) * 1e-3
         by = csr_bytes(nnz, M) + K * B * 4 + M * B * 4
+        streamed = nnz * 6 + K * B * 4 + M * B * 4
         out.append({"B": B, "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
-                    "frac_hbm": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "bytes": by})
+                    "frac_hbm": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "bytes": by,
+                    "frac_hbm_streamed": round(streamed / t / 1e9 / HBM_PEAK_GBS, 4), "kernel": ",".join(ss.path_last())})
     lib.ss_spmat_destroy(h)
-    return {"workload": f"W 100k x 100k, 1 percent dense (nnz {nnz}), fp32, CSR streamed once from HBM", "results": out}
+    return {"workload": f"W 100k x 100k, 1 percent dense (nnz {nnz}), fp32, CSR streamed once from HBM",
+            "frac_hbm": "algorithmic bytes (CSR 8 B/nnz + R + F) / time / 8 TB/s",
+            "frac_hbm_streamed": "bytes of the chunk-major operand the kernels read (6 B/nnz + R + F) / time / 8 TB/s",
+            "results": out}
 
 
-def bench_c3loo(args, ss, torch, dist, world, rank):
-    """BASELINE configs[2]: 100k x 100k, 1 %, leave-one-out; folds are block-sharded over the ranks
-    (ss.shard_range) and each step scores `--folds` consecutive folds of the rank's shard."""
+def build_c3(ss, torch):
     from tools.c3_loo import rand_csr, rand_sym_csr
     n = 100_000
     gen = torch.Generator(device="cuda")
@@ -135,74 +139,173 @@ def bench_c3loo(args, ss, torch, dist, world, rank):
     yp, yi = rand_csr(n, n, 0.01, gen)
     xv = (0.5 + 0.5 * torch.rand(xi.numel(), device="cuda", generator=gen)).float()
     g = ss.DeviceGraph.from_device_csr(0, n, n, n, None, (xp, xi, xv), (yp, yi, None), dtype=np.float32)
+    return g, n
+
+
+def c3_loo_curve(args, ss, torch, dist, world, rank, backend):
+    """BASELINE configs[2] on this run's ranks: 100k x 100k, 1 %, leave-one-out; the 10^5 folds are block-sharded
+    (ss.shard_range), every rank scores `--folds` consecutive folds of its shard per step (same per-rank work at every
+    N: weak scaling in the step, i.e. the full 10^5-fold job gets N times faster).  Reported without any exchange, with
+    the direct all-to-all gather of the score blocks, with a gather to rank 0 only, and with the reduced gather of the
+    top-L predictions per fold."""
+    g, n = build_c3(ss, torch)
     lo, hi = ss.shard_range(n, rank, world)
     folds = min(args.folds, hi - lo)
     out = torch.empty((folds, n), dtype=torch.float32, device="cuda")
+    steps = args.c3_steps
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    pos = lo
-    for _ in range(args.warmup):
-        g.predict_loo(pos, pos + folds, clean=True, out=out)
-    barrier()
-    ss.timing_hold(True)   # HIP-event stage timings add up over the timed region, read once after it
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        b = lo + (i * folds) % max(1, (hi - lo) - folds + 1)
-        g.predict_loo(b, b + folds, clean=True, out=out)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = ss.timing_last()
-    ss.timing_hold(False)
-    st = {"transfer_ms": [t["transfer_ms"] / max(1, t["transfer_launches"])],
-          "spmm_ms": [t["spmm_ms"] / max(1, t["spmm_launches"])]}
+    def run(exchange):
+        pos = lo
+        g.predict_loo(pos, pos + folds, clean=True, out=out)   # warm (operands are cut at first use)
+        if exchange:
+            exchange()
+        barrier()
+        ss.timing_hold(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            b = lo + (i * folds) % max(1, (hi - lo) - folds + 1)
+            g.predict_loo(b, b + folds, clean=True, out=out)
+            if exchange:
+                exchange()
+        barrier()
+        el = time.perf_counter() - t0
+        t = ss.timing_last()
+        ss.timing_hold(False)
+        if world > 1:
+            te = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el, t
+
+    counts = [folds] * world
+
+    def ex_all():
+        src = out if backend == "nccl" else out.cpu()
+        ss.gather_scores(src, folds * world, counts=counts)
+
+    def ex_root():
+        src = out if backend == "nccl" else out.cpu()
+        ss.gather_scores(src, folds * world, root=0, counts=counts)
+
+    def ex_topl():
+        ti, tv = ss.topl(out, 100)
+        if backend != "nccl":
+            ti, tv = ti.cpu(), tv.cpu()
+        ss.gather_topl(ti, tv, folds * world, counts=counts)
+
+    el0, t = run(None)
+    res = {"workload": "BASELINE configs[2]: 100k x 100k, 1%% density, leave-one-out, folds block-sharded over ranks; %d folds "
+                       "per rank and step, %d steps" % (folds, steps),
+           "nnz_X": g.nnz_xs, "nnz_Y": g.nnz_ys, "folds_per_rank_step": folds,
+           "folds_per_s": folds * world * steps / el0, "edges_per_s": folds * world * steps * n / el0,
+           "ms_per_step": el0 / steps * 1e3,
+           "stage1_ms": t["transfer_ms"] / max(1, t["transfer_launches"]), "stage2_ms": t["spmm_ms"] / max(1, t["spmm_launches"]),
+           "full_loo_seconds_at_this_rate": n / (folds * world * steps / el0)}
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" else "cpu")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        el1, _ = run(ex_all)
+        el2, _ = run(ex_root)
+        res["with_gather_all_ranks"] = {"folds_per_s": folds * world * steps / el1, "ms_per_step": el1 / steps * 1e3,
+                                        "bytes_received_per_rank_step": folds * (world - 1) * n * 4,
+                                        "how": "direct point-to-point exchange of exact row blocks (grouped ncclSend/ncclRecv)"}
+        res["with_gather_to_rank0"] = {"folds_per_s": folds * world * steps / el2, "ms_per_step": el2 / steps * 1e3}
+    el3, _ = run(ex_topl if world > 1 else (lambda: ss.topl(out, 100)))
+    res["with_topL_reduction_L100"] = {"folds_per_s": folds * world * steps / el3, "ms_per_step": el3 / steps * 1e3,
+                                       "bytes_received_per_rank_step": folds * (world - 1) * 100 * 8,
+                                       "how": "ss_topl_f32 on the device, then the same exchange on 100 (column, score) pairs per fold"}
+    g.close()
+    return res
+
+
+def bench_c3loo(args, ss, torch, dist, world, rank, backend):
+    """--workload c3loo: the configs[2] curve as the headline line (the default line carries it as `c3_loo`)."""
+    res = c3_loo_curve(args, ss, torch, dist, world, rank, backend)
     if rank == 0:
-        spmm_ms = float(np.mean(st["spmm_ms"]))
-        flops = 2.0 * g.nnz_ys * folds
-        by = csr_bytes(g.nnz_ys, n) + n * folds * 4 * 2
+        n = 100_000
+        flops = 2.0 * res["nnz_Y"] * res["folds_per_rank_step"]
+        by = csr_bytes(res["nnz_Y"], n) + n * res["folds_per_rank_step"] * 4 * 2
         print(json.dumps({
-            "metric": "predicted edges/sec + achieved HBM GB/s, W*R SpMM", "value": folds * n * world / (elapsed / args.steps),
-            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 100k x 100k, 1%% density, leave-one-out folds block-sharded over "
-                                   "ranks, %d folds per rank and step" % folds, "nnz_X": g.nnz_xs, "nnz_Y": g.nnz_ys,
-                       "folds_per_s_per_gpu": folds / (elapsed / args.steps)},
-            "roofline": {"kernel": "spmm_sell_kernel<float,4> (stage 2, B = %d folds, 10 LDS chunks of W)" % folds,
-                         "bound": "mfma", "achieved": round(flops / (spmm_ms * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(flops / (spmm_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                         "traffic": None, "avg_launch_ms": round(spmm_ms, 4), "algorithmic_bytes": by,
-                         "frac_hbm": round(by / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "stage1_transfer_ms": round(float(np.mean(st["transfer_ms"])), 4)}}))
+            "metric": "predicted edges/sec + achieved HBM GB/s, W*R SpMM", "value": res["edges_per_s"],
+            "unit": "edges/s", "n_gpus": world, "steps": args.c3_steps, "warmup": 1,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": {"workload": res["workload"]},
+            "roofline": {"kernel": "spmm_sell_kernel<float,4,true> (stage 2, B = %d folds)" % res["folds_per_rank_step"],
+                         "bound": "hbm", "achieved": round(by / (res["stage2_ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(by / (res["stage2_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_ms": round(res["stage2_ms"], 4), "algorithmic_bytes": by,
+                         "frac_fp32_fma": round(flops / (res["stage2_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                         "note": "at B = thousands of columns the kernel is bound by LDS gathers / fp32 FMA issue, not by HBM"},
+            "c3_loo": res}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def literal_dense_baseline(ss, n_small, dx, dy):
+    """The reference path itself, literally (src/core.jl:365-371,402-423): dense N x N block adjacency A, B = A with the
+    query rows/columns zeroed, W = spread(B) (row counts, Inf/NaN -> 0), F = A * (W * W), the queries x targets corner
+    -- fp64 through numpy / OpenBLAS dgemm, the BLAS SimSpread.jl's `*` dispatches to.  Down-scaled C2 (N = 4 n_small
+    nodes: the full C2 would need 12.8 GB per N x N array and 2.6e14 flop), same densities, same generator; the GPU
+    scores the same down-scaled input for the error figure."""
+    import scipy.sparse as sp
+    Xq, Xs, Ys = synth_c2(n_small, n_small, n_small, n_small, dx, dy, seed=20250222 + 2, rank=0, weighted=True)
+    q, s, f, t = n_small, n_small, n_small, n_small
+    A = sp.bmat([[None, None, Xq, None], [None, None, Xs, Ys], [Xq.T, Xs.T, None, None], [None, Ys.T, None, None]],
+                format="csr", dtype=np.float64)
+    A = np.asarray(A.toarray(), dtype=np.float64)       # node order [queries; sources; features; targets] (src/core.jl:182-195)
+    N = A.shape[0]
+    assert N == q + s + f + t
+    t0 = time.perf_counter()
+    B = A.copy()                                        # deepcopy + zero the query rows/columns (src/core.jl:196-198)
+    B[:q, :] = 0.0
+    B[:, :q] = 0.0
+    k = np.count_nonzero(B, axis=1).astype(np.float64)[:, None]   # k(G): non-zero count per row (src/graphs.jl:9-11)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        W = B / k
+    W[~np.isfinite(W)] = 0.0                            # Inf, NaN -> 0 (src/core.jl:367-368)
+    F = A @ (W @ W)                                     # src/core.jl:413: A * W^2, power_by_squaring == W*W
+    yhat = F[:q, q + s + f:]                            # F[names(ytest,1), names(ytest,2)] (src/core.jl:421)
+    dt = time.perf_counter() - t0
+    g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+    got = g.predict("query")
+    g.close()
+    err = float(np.abs(got - yhat).max() / np.abs(yhat).max())
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [os.cpu_count()])
+    except Exception:
+        thr = os.cpu_count()
+    return {"value": q * t / dt, "unit": "edges/s", "cores": int(thr), "kind": "port",
+            "what": "literal dense restatement of src/core.jl:365-371,402-423 (A, B, spread, A*(W*W)) in fp64 on numpy/OpenBLAS dgemm "
+                    "-- the BLAS the reference's `*` calls; Julia is not installed, so SimSpread.jl itself cannot be timed",
+            "sample": "down-scaled C2: %d queries x %d targets, N = %d nodes (2 x N^3 x 2 = %.2e flop), one pass, %.1f s"
+                      % (q, t, N, 4.0 * N ** 3, dt),
+            "wall_s": dt, "gflops": 4.0 * N ** 3 / dt / 1e9, "max_rel_err_gpu_vs_cpu": err}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300, help="timed predict() passes (300 x ~2 ms: a >= 0.5 s timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--n", type=int, default=10_000, help="sources = features = targets")
     ap.add_argument("--dx", type=float, default=0.05)
     ap.add_argument("--dy", type=float, default=0.01)
     ap.add_argument("--unweighted", action="store_true", help="binary similarity features (featurize(..., weighted=false))")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3loo"],
-                    help="c2: BASELINE configs[1] (default, the metric's config); c3loo: configs[2], 100k x 100k 1%% "
-                         "leave-one-out, each rank scores --folds consecutive folds of its shard per step")
-    ap.add_argument("--folds", type=int, default=2048, help="c3loo: folds per rank and step")
+                    help="c2: BASELINE configs[1] (default, the metric's config); c3loo: configs[2] as the headline line")
+    ap.add_argument("--folds", type=int, default=2048, help="configs[2]: folds per rank and step")
+    ap.add_argument("--c3-steps", type=int, default=5, help="configs[2]: timed steps")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="compute type (the metric's config is f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the score blocks (outside `value`)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the configs[2] leave-one-out curve")
+    ap.add_argument("--dense-n", type=int, default=3000, help="literal dense CPU baseline: nodes per layer (N = 4x this)")
+    ap.add_argument("--gather", action="store_true", help="also time the final gather of the C2 score blocks (outside `value`)")
     args = ap.parse_args()
 
     import torch
@@ -230,7 +333,7 @@ def main():
     ss.use_torch_stream()  # device buffers come from torch: share its stream
 
     if args.workload == "c3loo":
-        return bench_c3loo(args, ss, torch, dist, world, rank)
+        return bench_c3loo(args, ss, torch, dist, world, rank, backend)
 
     nq, n = args.nq, args.n
     Xq, Xs, Ys = synth_c2(nq, n, n, n, args.dx, args.dy, seed=20250222 + 2, rank=rank, weighted=not args.unweighted)
@@ -246,7 +349,7 @@ def main():
     for _ in range(args.warmup):
         g.predict("query", out=scores)
     barrier()
-    ss.timing_hold(True)   # HIP-event stage timings add up over the timed region, read once after it
+    ss.timing_hold(True)   # HIP-event stage timings (on the stream the kernels run on) add up over the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         g.predict("query", out=scores)   # enqueued in stream order; the barrier below waits for all K steps
@@ -254,9 +357,10 @@ def main():
     elapsed = time.perf_counter() - t0
     t = ss.timing_last()
     ss.timing_hold(False)
+    path = ss.path_last()
     # average duration of one launch of each kernel over the timed region (one launch per stage and step here)
-    stage = {"transfer_ms": [t["transfer_ms"] / max(1, t["transfer_launches"])],
-             "spmm_ms": [t["spmm_ms"] / max(1, t["spmm_launches"])], "total_ms": [t["total_ms"] / args.steps]}
+    transfer_ms = t["transfer_ms"] / max(1, t["transfer_launches"])
+    spmm_ms = t["spmm_ms"] / max(1, t["spmm_launches"])
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -267,51 +371,62 @@ def main():
 
     gather_ms = None
     if args.gather and world > 1:
-        bufs = [torch.empty_like(scores) for _ in range(world)]
+        src = scores if backend == "nccl" else scores.cpu()
         barrier()
         tg = time.perf_counter()
-        dist.all_gather(bufs, scores)
+        ss.gather_scores(src, nq * world, counts=[nq] * world)
         barrier()
         gather_ms = (time.perf_counter() - tg) * 1e3
 
+    c3 = None
+    if not args.no_c3:
+        try:
+            c3 = c3_loo_curve(args, ss, torch, dist, world, rank, backend)
+        except Exception as e:  # auxiliary: never lose the headline line
+            c3 = {"error": repr(e)}
+
     if rank == 0:
         nnz_w = g.nnz_ys
-        spmm_ms = float(np.mean(stage["spmm_ms"]))
-        transfer_ms = float(np.mean(stage["transfer_ms"]))
-        # dominant kernel: the W*R SpMM (stage 2).  Algorithmic work per launch:
-        #   bytes = CSR(W) + K*B*4 + M*B*4,  flops = 2*nnz(W)*B,  B = nq columns of R per launch
+        tname = "float" if args.dtype == "f32" else "double"
+        # ---- dominant kernel of the step: stage 1 (sparse x sparse -> dense transfer block).  Algorithmic bytes per
+        # launch: its inputs once (CSR(Xq) + CSR(Xs)) and its output once (T, nq x ns values); flops
+        # 2 * nnz(Xq) * mean row length of Xs'.
+        s1_bytes = csr_bytes(g.nnz_xq, nq, vb) + csr_bytes(g.nnz_xs, n, vb) + nq * n * vb
+        s1_flops = 2.0 * g.nnz_xq * (g.nnz_xs / n)
+        s1_pmc, s1_src = pmc_entry("transfer_kernel")
+        s1_gbps = s1_bytes / (transfer_ms * 1e-3) / 1e9
+        roofline = {
+            "kernel": "transfer_kernel<%s> (stage 1, T = (Xq Df^-1) Xs' Ds^-1; %d%% of the step)"
+                      % (tname, round(100 * transfer_ms / max(transfer_ms + spmm_ms, 1e-9))),
+            "bound": "hbm", "achieved": round(s1_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(s1_gbps / HBM_PEAK_GBS, 4),
+            "traffic": s1_pmc["hbm_bytes_per_launch"] if s1_pmc else None, "traffic_source": s1_src,
+            "avg_launch_ms": round(transfer_ms, 4), "algorithmic_bytes": s1_bytes,
+            "flops": s1_flops, "frac_fp32_fma": round(s1_flops / (transfer_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+            "limiter": "not HBM: every query re-reads 5 % of X' as ~62-entry sub-rows from its XCD's L2 (95 % hits); the L2 -> L1 "
+                       "path moves 64 B per request and clock and channel (measured ceiling 18.7 TB/s for this access pattern, "
+                       "tools/subrow_fetch_bench.hip) and the sub-row sectors add up to ~18.5 GB per launch (DESIGN.md 4.1)",
+            "l2_request_bytes": s1_pmc["l2_request_bytes_per_launch"] if s1_pmc else None,
+            "frac_l2_sector_ceiling": (round(s1_pmc["l2_request_bytes_per_launch"] / (transfer_ms * 1e-3) / 1e9 / 18700.0, 4)
+                                       if s1_pmc else None),
+        }
+        # ---- the W*R SpMM of the step (stage 2).  Algorithmic work per launch:
+        #   bytes = CSR(W) + K*B*vb + M*B*vb,  flops = 2*nnz(W)*B,  B = nq columns of R per launch
         spmm_bytes = csr_bytes(nnz_w, n, vb) + n * nq * vb + n * nq * vb
         spmm_flops = 2.0 * nnz_w * nq
+        s2_pmc, s2_src = pmc_entry("spmm_sell_kernel")
         achieved_tf = spmm_flops / (spmm_ms * 1e-3) / 1e12
-        roofline = {
+        roofline_spmm = {
             "kernel": "spmm_sell_kernel<%s> (stage 2, F = W*R, B = %d)" % ("float,4" if args.dtype == "f32" else "double,2", nq),
-            "bound": "mfma",
-            "bound_note": "wide-R SpMM is FMA/LDS-gather bound; peak = fp32 vector rate = fp32-input MFMA rate (157.3 TF)",
+            "bound": "fp32 vector FMA rate (no MFMA is issued; peak 157.3 TF = 256 CUs x 128 FMA/clk x 2.4 GHz); in practice the "
+                     "LDS gather: one ds_read_b128 per four FMAs caps this formulation at 50 % of that peak",
             "achieved": round(achieved_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4),
-            "traffic": pmc_traffic("spmm_sell_kernel"),
+            "traffic": s2_pmc["hbm_bytes_per_launch"] if s2_pmc else None, "traffic_source": s2_src,
             "avg_launch_ms": round(spmm_ms, 4),
             "algorithmic_bytes": spmm_bytes,
             "algorithmic_GBps": round(spmm_bytes / (spmm_ms * 1e-3) / 1e9, 1),
             "frac_hbm": round(spmm_bytes / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "predict_algorithmic_bytes": csr_bytes(g.nnz_xq, nq) + csr_bytes(g.nnz_xs, n) + csr_bytes(nnz_w, n) + nq * n * 4,
-        }
-        # stage 1 (sparse x sparse -> dense transfer block) is the longer kernel at this shape; it is bound by
-        # LDS scatter throughput (73 % LDS-busy in profiles/), not by HBM or FMA -- both fractions are reported
-        s1_bytes = csr_bytes(g.nnz_xq, nq) + csr_bytes(g.nnz_xs, n) + nq * n * 4
-        s1_flops = 2.0 * g.nnz_xq * (g.nnz_xs / n)
-        stage1 = {
-            "kernel": "transfer_kernel<float,false,8> (stage 1, T = (Xq Df^-1) Xs' Ds^-1)",
-            "avg_launch_ms": round(transfer_ms, 4),
-            "bound": "L2 bandwidth for short runs (DESIGN.md 4.1): every query re-reads 5 % of X' as ~62-entry sub-rows; "
-                     "tools/subrow_fetch_bench.hip measures 18.7 TB/s as the chip's ceiling for that pattern",
-            "l2_bytes": pmc_field("transfer_kernel", "l2_request_bytes_per_launch"),
-            "l2_peak_GBps_measured": 18700.0,
-            "frac_l2": (round(pmc_field("transfer_kernel", "l2_request_bytes_per_launch") / (transfer_ms * 1e-3) / 1e9 / 18700.0, 4)
-                        if pmc_field("transfer_kernel", "l2_request_bytes_per_launch") else None),
-            "algorithmic_bytes": s1_bytes, "frac_hbm": round(s1_bytes / (transfer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "flops": s1_flops, "frac_fma": round(s1_flops / (transfer_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-            "traffic": pmc_traffic("transfer_kernel"),
         }
         result = {
             "metric": "predicted edges/sec + achieved HBM GB/s, W*R SpMM",
@@ -323,12 +438,16 @@ def main():
                                    % (nq, n, n, args.dx * 100, "unweighted" if args.unweighted else "weighted U(0.5,1]",
                                       args.dy * 100),
                        "queries_per_gpu": nq, "sources": n, "features": n, "targets": n,
-                       "nnz_Xq": g.nnz_xq, "nnz_Xs": g.nnz_xs, "nnz_Ys": g.nnz_ys, "sharding": "query rows, no collective"},
+                       "nnz_Xq": g.nnz_xq, "nnz_Xs": g.nnz_xs, "nnz_Ys": g.nnz_ys, "sharding": "query rows, no collective",
+                       "kernels": path, "timed_region_s": round(elapsed, 3),
+                       "predict_algorithmic_bytes": csr_bytes(g.nnz_xq, nq) + csr_bytes(g.nnz_xs, n) + csr_bytes(nnz_w, n) + nq * n * 4},
             "roofline": roofline,
-            "roofline_stage1": stage1,
+            "roofline_spmm": roofline_spmm,
         }
         if gather_ms is not None:
             result["score_gather_ms"] = gather_ms
+        if c3 is not None:
+            result["c3_loo"] = c3
         if not args.no_sweep and world == 1:
             try:
                 result["spmm_narrow_sweep"] = spmm_sweep(ss, torch)
@@ -337,29 +456,38 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from oracle import c_oracle
             f64 = [m.astype(np.float64) for m in (Xq, Xs, Ys)]
-            c_oracle.predict_query(*f64, r0=0, r1=8)  # warm
-            # bounded sample: whole passes over the same query block until ~10 s of CPU work are done
-            nsample, reps, dt = min(nq, 512), 0, 0.0
+            # the graph-dependent part (transposes, reciprocal degrees) is prepared once, outside the timed body -- like
+            # the GPU path, whose operands are resident when its timed region starts
+            prep = c_oracle.Prepared(*f64)
+            prep.predict(0, 8)  # warm
+            nsample = min(nq, 512)
             tc = time.perf_counter()
-            ref = c_oracle.predict_query(*f64, r0=0, r1=nsample)
+            ref = prep.predict(0, nsample)
             first = time.perf_counter() - tc
             rows_per_pass = nq if first * nq / nsample < 20.0 else nsample
-            rows_done = 0
+            buf = np.empty((rows_per_pass, n))
+            rows_done, reps, dt = 0, 0, 0.0
             tc = time.perf_counter()
-            while dt < 10.0 and reps < 50:
-                ref = c_oracle.predict_query(*f64, r0=0, r1=rows_per_pass)
+            while dt < 10.0 and reps < 50:   # bounded sample: whole passes over the same query block, ~10 s of CPU work
+                ref = prep.predict(0, rows_per_pass, out=buf)
                 rows_done += rows_per_pass
                 reps += 1
                 dt = time.perf_counter() - tc
             got = scores[:rows_per_pass].cpu().numpy()
             err = float(np.abs(got - ref).max() / np.abs(ref).max())
+            prep.close()
             result["cpu_baseline"] = {
                 "value": rows_done * n / dt, "unit": "edges/s", "cores": c_oracle.max_threads(), "kind": "port",
                 "sample": "%d passes over the first %d of %d query rows of the same workload, fp64 CSR C/OpenMP "
-                          "restatement of the reference algorithm (oracle/factored.c; Julia is not installed, so "
-                          "SimSpread.jl itself cannot be timed), %.1f s" % (reps, rows_per_pass, nq, dt),
+                          "restatement of the reference algorithm in its factored form (oracle/factored.c, operands prepared "
+                          "outside the timed body; Julia is not installed, so SimSpread.jl itself cannot be timed), %.1f s"
+                          % (reps, rows_per_pass, nq, dt),
                 "max_rel_err_gpu_vs_cpu": err,
             }
+            try:
+                result["cpu_baseline"]["literal_dense"] = literal_dense_baseline(ss, args.dense_n, args.dx, args.dy)
+            except Exception as e:
+                result["cpu_baseline"]["literal_dense"] = {"error": repr(e)}
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

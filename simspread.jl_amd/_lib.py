@@ -152,3 +152,17 @@ def path_last() -> list:
     buf = C.create_string_buffer(512)
     check(lib().ss_path_last(C.cast(buf, C.c_void_p), 512))
     return [t for t in buf.value.decode().split(",") if t]
+
+
+def source_hash() -> str:
+    """Short hash of the kernel sources (csrc/*.hip, *.hpp): profiles/ records it next to the PMC numbers so that a
+    consumer (bench.py) can tell whether the counters were taken from the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:12]

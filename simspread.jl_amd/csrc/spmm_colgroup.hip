@@ -60,21 +60,18 @@ struct alignas(16) ColPack {
   T v[N];
 };
 
-// DPP quad_perm inside each group of four lanes: CTRL 0x00 = every lane takes lane 0's value (broadcast),
-// 0x39 = lane i takes lane (i + 1) % 4's value (rotate)
+// DPP quad_perm inside each group of four lanes: CTRL = 0x55 * e makes every lane take lane e's value (broadcast)
 template <class T, int CTRL>
-__device__ __forceinline__ T dpp_quad(T v);
-template <> __device__ __forceinline__ float dpp_quad<float, 0x00>(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x00, 0xF, 0xF, true)); }
-template <> __device__ __forceinline__ float dpp_quad<float, 0x39>(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x39, 0xF, 0xF, true)); }
-#define SS_DPP_F64(CTRL)                                                                           \
-  template <> __device__ __forceinline__ double dpp_quad<double, CTRL>(double v) {                 \
-    const long long b = __double_as_longlong(v);                                                   \
-    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true); \
-    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);          \
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);                         \
+__device__ __forceinline__ T dpp_quad(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+  } else {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
   }
-SS_DPP_F64(0x00) SS_DPP_F64(0x39)
-#undef SS_DPP_F64
+}
 
 template <class T, int BV, int NP, bool BIN, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) spmm_colgroup_kernel(ColArgs<T> a) {
@@ -85,7 +82,7 @@ __global__ void __launch_bounds__(WAVES * 64) spmm_colgroup_kernel(ColArgs<T> a)
   constexpr int RSH = ROWB == 256 ? 8 : (ROWB == 128 ? 7 : 6);
   constexpr int NCG = ROWB / 16;             // 16-byte slots per tile row
   constexpr int CPL = NR * PW;               // columns per lane
-  constexpr int NBQ = ROWB == 64 ? 2 : 1;    // batches of four quads requested ahead per row (mean sub-row: 23 / 12 / 6 entries)
+  constexpr int NBQ = ROWB == 256 ? 1 : 2;   // batches of four quads (16 entries) requested ahead per row: mean sub-row 23 / 11 / 6 entries, so that the slow path below stays rare
   // row sets whose first batches are in flight (measured at 100k x 100k, 1 %: 1, 2 and 3 differ by < 5 % -- the kernel is
   // bound by instruction issue, not by the latency of the W stream)
   constexpr int AHEAD = COL_AHEAD_OVERRIDE ? COL_AHEAD_OVERRIDE : (BIN ? 2 : 1);
@@ -214,33 +211,30 @@ __global__ void __launch_bounds__(WAVES * 64) spmm_colgroup_kernel(ColArgs<T> a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // gathers of one batch of (up to four) quads held by lanes cl = 0 .. nq-1 of each group: a rolled loop broadcasts
-    // lane 0's quad and then rotates the quads of the group by one lane (DPP quad_perm, no LDS traffic).  No memory
-    // loads in here: the waits for the prefetched quads stay counted (a load inside would turn them into vmcnt(0))
-    auto batch = [&](int p, int nq, uint2 iv, Q w) __attribute__((always_inline)) {
+    // gathers of one batch of (up to four) quads held by lanes cl = 0 .. nq-1 of each group: quad e is broadcast from
+    // lane e of the group by DPP quad_perm (no LDS traffic; the four copies below differ only in the lane they read).
+    // No memory loads in here: the waits for the prefetched quads stay counted (a load inside would turn them into
+    // vmcnt(0)).
+    auto batch = [&](int p, int nq, const uint2 iv, const Q w) __attribute__((always_inline)) {
       if (a.dbg & 2) { acc[p][0] += __uint_as_float(iv.x) + (BIN ? T(0) : w.v[0]); nq = 0; }
-      for (int e = 0; e < nq; ++e) {
-        const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.x, 0x00, 0xF, 0xF, true);
-        const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.y, 0x00, 0xF, 0xF, true);
-        T w0 = T(0), w1 = T(0), w2 = T(0), w3 = T(0);
-        if (!BIN) {
-          w0 = dpp_quad<T, 0x00>(w.v[0]); w1 = dpp_quad<T, 0x00>(w.v[1]);
-          w2 = dpp_quad<T, 0x00>(w.v[2]); w3 = dpp_quad<T, 0x00>(w.v[3]);
-        }
-        entry(p, x & 0xffffu, w0);
-        entry(p, x >> 16, w1);
-        // weighted variants: keep the scheduler from gathering all four tile rows (up to 64 registers) at once
-        if (!BIN) __builtin_amdgcn_sched_barrier(0);
-        entry(p, y & 0xffffu, w2);
-        entry(p, y >> 16, w3);
-        // rotate: lane cl takes the quad of lane cl + 1
-        iv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.x, 0x39, 0xF, 0xF, true);
-        iv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.y, 0x39, 0xF, 0xF, true);
-        if (!BIN) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) w.v[i] = dpp_quad<T, 0x39>(w.v[i]);
-        }
+#define SS_COL_QUAD(E, CTRL)                                                                      \
+      if (E < nq) {                                                                               \
+        const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.x, CTRL, 0xF, 0xF, true);   \
+        const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.y, CTRL, 0xF, 0xF, true);   \
+        T w0 = T(0), w1 = T(0), w2 = T(0), w3 = T(0);                                             \
+        if (!BIN) {                                                                               \
+          w0 = dpp_quad<T, CTRL>(w.v[0]); w1 = dpp_quad<T, CTRL>(w.v[1]);                         \
+          w2 = dpp_quad<T, CTRL>(w.v[2]); w3 = dpp_quad<T, CTRL>(w.v[3]);                         \
+        }                                                                                         \
+        entry(p, x & 0xffffu, w0);                                                                \
+        entry(p, x >> 16, w1);                                                                    \
+        /* weighted variants: keep the scheduler from gathering all four tile rows (64 registers) at once */ \
+        if (!BIN) __builtin_amdgcn_sched_barrier(0);                                              \
+        entry(p, y & 0xffffu, w2);                                                                \
+        entry(p, y >> 16, w3);                                                                    \
       }
+      SS_COL_QUAD(0, 0x00) SS_COL_QUAD(1, 0x55) SS_COL_QUAD(2, 0xAA) SS_COL_QUAD(3, 0xFF)
+#undef SS_COL_QUAD
     };
     bool longer = false;  // some row of this lane group has more quads in this chunk than were prefetched
 #pragma unroll

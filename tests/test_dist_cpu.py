@@ -37,7 +37,7 @@ def test_shard_range_weighted_balances_power_law_rows():
     assert loads.max() <= eq.max() + 1e-9
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, use_hip):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -46,23 +46,73 @@ def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    Xq, Xs, Ys = O.synth_bipartite(37, 60, 60, 23, 0.2, 0.1, seed=5, dtype=np.float64)
+    nq = 37 if not use_hip else 301                      # uneven blocks in both cases
+    Xq, Xs, Ys = O.synth_bipartite(nq, 60 if not use_hip else 900, 60 if not use_hip else 900, 23 if not use_hip else 257,
+                                   0.2 if not use_hip else 0.05, 0.1 if not use_hip else 0.03, seed=5,
+                                   dtype=np.float64 if not use_hip else np.float32)
     lo, hi = ss.shard_range(Xq.shape[0], rank, world)
-    local = torch.from_numpy(O.predict_factored(Xq[lo:hi], Xs, Ys))   # stand-in for DeviceGraph.predict on this rank
-    full = ss.gather_scores(local, Xq.shape[0])
+    if use_hip:
+        # the HIP path on every rank: the ranks share device 0 of a one-GPU box (the 8-GPU run gives each its own);
+        # the whole graph is replicated, the rank scores only its block of query rows -- no data-path collective
+        ss.init(0)
+        g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+        local = torch.from_numpy(g.predict("query", row_begin=lo, row_end=hi).copy())
+        top_i, top_v = ss.topl(local.numpy(), 5)
+        top_i, top_v = torch.from_numpy(top_i.copy()), torch.from_numpy(top_v.copy())
+    else:
+        local = torch.from_numpy(O.predict_factored(Xq[lo:hi], Xs, Ys))   # stand-in for DeviceGraph.predict on this rank
+        order = np.argsort(-local.numpy(), axis=1, kind="stable")[:, :5]
+        top_i = torch.from_numpy(order.astype(np.int32))
+        top_v = torch.from_numpy(np.take_along_axis(local.numpy(), order, axis=1))
+    counts = [ss.shard_range(Xq.shape[0], r, world)[1] - ss.shard_range(Xq.shape[0], r, world)[0] for r in range(world)]
+    full = ss.gather_scores(local, Xq.shape[0])                                   # every rank gets the matrix
+    at_root = ss.gather_scores(local, Xq.shape[0], root=1, counts=counts)           # only rank 1 does
+    assert (at_root is None) == (rank != 1)
+    if rank == 1:
+        assert torch.equal(at_root, full)
+    gi, gv = ss.gather_topl(top_i, top_v, Xq.shape[0], counts=counts)              # reduced gather: L numbers per row
     np.save(os.path.join(tmp, f"full_{rank}.npy"), full.numpy())
+    np.save(os.path.join(tmp, f"topi_{rank}.npy"), gi.numpy())
+    np.save(os.path.join(tmp, f"topv_{rank}.npy"), gv.numpy())
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def test_two_rank_gloo_sharded_predict_and_gather(tmp_path):
     import torch.multiprocessing as mp
     from oracle import simspread_oracle as O
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), False), nprocs=2, join=True)
     Xq, Xs, Ys = O.synth_bipartite(37, 60, 60, 23, 0.2, 0.1, seed=5, dtype=np.float64)
     want = O.predict_factored(Xq, Xs, Ys)
+    order = np.argsort(-want, axis=1, kind="stable")[:, :5]
     for r in range(2):
         np.testing.assert_array_equal(np.load(tmp_path / f"full_{r}.npy"), want)
+        np.testing.assert_array_equal(np.load(tmp_path / f"topi_{r}.npy"), order)
+        np.testing.assert_array_equal(np.load(tmp_path / f"topv_{r}.npy"), np.take_along_axis(want, order, axis=1))
+
+
+@pytest.mark.gpu
+def test_two_rank_hip_path_equals_single_process_bit_for_bit(tmp_path):
+    """The N > 1 path with the HIP kernels on every rank (two processes sharing the box's one GPU, gloo for the
+    exchange): the gathered matrix must equal the single-process prediction bit for bit -- rows are scored
+    independently of how they are blocked -- and the reduced top-L gather must equal top-L of the full matrix."""
+    import torch.multiprocessing as mp
+    import simspread_jl_amd as ss
+    from oracle import simspread_oracle as O
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    Xq, Xs, Ys = O.synth_bipartite(301, 900, 900, 257, 0.05, 0.03, seed=5, dtype=np.float32)
+    ss.init(0)
+    single = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32).predict("query").copy()
+    ti, tv = ss.topl(single, 5)
+    want = O.predict_factored(Xq.astype(np.float64), Xs.astype(np.float64), Ys.astype(np.float64))
+    assert np.abs(single - want).max() / np.abs(want).max() < 1e-5
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"full_{r}.npy"), single)
+        assert np.array_equal(np.load(tmp_path / f"topi_{r}.npy"), ti)
+        assert np.array_equal(np.load(tmp_path / f"topv_{r}.npy"), tv)

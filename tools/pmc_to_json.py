@@ -3,6 +3,8 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from simspread_jl_amd import _lib
 def avg(counter_dir, counter):
     agg = defaultdict(list)
     for f in glob.glob(os.path.join(src, counter_dir, "**", "*counter_collection.csv"), recursive=True):
@@ -21,14 +23,16 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recurs
     with open(f) as fh:
         for r in csv.DictReader(fh):
             dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 5 --warmup 2`",
-       "units": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 5 --warmup 2 --no-sweep --no-cpu-baseline --no-c3`",
+       "source_sha": _lib.source_hash(),
+       "units": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies the 128-B requests of wide streaming reads at 64 B, MI355X_MICROARCH.md; for the 2-4 byte-per-lane loads of transfer_kernel the factor is uncalibrated, so hbm_bytes_unscaled = (FETCH_SIZE + WRITE_SIZE)*1024 is given too; both count Infinity-Cache hits as memory traffic)",
        "kernels": {}}
 for k in fetch:
-    if not any(s in k for s in ("transfer_kernel", "spmm_sell", "spmm_csr")):
+    if not any(s in k for s in ("transfer", "spmm", "reduce_kernel", "unpermute")):
         continue
     out["kernels"][k] = {"FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write.get(k),
                          "hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0)) * 1024,
+                         "hbm_bytes_unscaled": (fetch[k] + write.get(k, 0)) * 1024,
                          "l2_request_bytes_per_launch": l2req.get(k, 0) * 64,
                          "l2_hit_rate": (l2hit.get(k, 0) / l2req[k]) if l2req.get(k) else None,
                          "lds_busy_frac": ((ldsact.get(k, 0) / 256) / (grbm[k] / 8)) if grbm.get(k) else None,

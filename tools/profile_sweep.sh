@@ -1,5 +1,8 @@
 #!/bin/bash
-# PMC passes over the narrow/mid W*R sweep (tools/sweep.py).  usage: SWEEP_B=16 tools/profile_sweep.sh <tag>
+# rocprofv3 passes over the narrow / mid W*R sweep (tools/sweep.py): kernel trace + stats, then FETCH_SIZE, WRITE_SIZE
+# (separate passes, MI355X_MICROARCH.md) and the LDS / issue counters.  Summaries land in gpurun_out/prof_<tag>
+# (copy summary.txt and the kernel stats into profiles/).
+# usage: SWEEP_B=1,4,8,16,32,64 tools/profile_sweep.sh <tag>      (SWEEP_BINARY=1: pattern-only W; SS_COL=0: older kernels)
 set -u
 TAG=${1:-sweep}
 export TMPDIR=/tmp
@@ -7,24 +10,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/sweep.py > $OUT/trace.log 2>&1
-for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 tools/sweep.py > $OUT/pmc_$name.log 2>&1
 done
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
-out = sys.argv[1]
-for d in sorted(glob.glob(out + "/pmc_*/")):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"][:60]
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            n[(k, r["Counter_Name"])] += 1
-    for k in acc:
-        if "spmm" in k:
-            print(k)
-            for c, v in acc[k].items():
-                print("   %-24s %.4g per launch" % (c, v / n[(k, c)]))
-PY
+python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
