@@ -64,10 +64,14 @@ class NamedMatrix:
             c = [ci[str(n)] for n in cols]
         except KeyError as e:
             raise KeyError(f"name {e} not found") from None
-        return NamedMatrix(self.array[np.ix_(r, c)], [str(n) for n in rows], [str(n) for n in cols])
+        out = NamedMatrix(self.array[np.ix_(r, c)], [str(n) for n in rows], [str(n) for n in cols])
+        out.integer = self.integer          # indexing an Int NamedArray gives an Int NamedArray in Julia
+        return out
 
     def copy(self) -> "NamedMatrix":
-        return NamedMatrix(self.array.copy(), list(self.rows), list(self.cols))
+        out = NamedMatrix(self.array.copy(), list(self.rows), list(self.cols))
+        out.integer = self.integer
+        return out
 
     def __eq__(self, other):  # NamedArrays `==` compares values only
         if isinstance(other, NamedMatrix):
@@ -394,6 +398,43 @@ def save(filepath: str, *args, delimiter: str = "\t") -> None:
                 row = [str(pos if fidx is None else fidx), f'"{q}"', f'"{t}"',
                        show(yhat, yhat.array[qi[q], ti[t]]), show(y, y.array[yq[q], yt[t]])]
                 f.write(delimiter.join(row) + "\n")
+
+
+def save_loo(filepath: str, y: NamedMatrix, X: NamedMatrix, delimiter: str = "\t", block: int = 1024,
+             precision: str = "f64", clean_scores: bool = True, graph: Optional[DeviceGraph] = None) -> int:
+    """The reference's leave-one-out loop with its output step, streamed from device score blocks:
+
+        for (i, s) in enumerate(names(y, 1))                       # user loop over construct's fold form
+            A, B = construct(y, X, [s]); yhat = predict((A, B), y[[s], :]); clean!(yhat, A, y[[s], :])
+            save(filepath, i, yhat, y[[s], :]; delimiter)           # src/core.jl:542-561
+
+    All folds come from ONE resident graph (ss_predict_loo_*); `block` folds are scored at a time, copied to the
+    host and appended as text in exactly save's wire format (fold, "source", "target", score, label), so the
+    full score matrix never exists on the host (BASELINE configs[2]: 40 GB) and an interrupted run can be resumed
+    at a block boundary (the file is opened in append mode, like the reference's).  Returns the number of lines."""
+    if y.shape[0] != X.shape[0]:
+        raise AssertionError("Labels and features have different number of source nodes")
+    g = graph if graph is not None else DeviceGraph.from_dense(None, X.array, y.array, alpha=None,
+                                                               dtype=_dev_dtype(precision))
+    sources, targets = y.names(1), y.names(2)
+    ns = len(sources)
+    quoted_t = [f'"{t}"' for t in targets]
+    show_y = (lambda v: _julia_number(int(v))) if getattr(y, "integer", False) else _julia_number
+    lines = 0
+    with open(filepath, "a+") as f:
+        for lo in range(0, ns, block):
+            hi = min(ns, lo + block)
+            scores = np.asarray(g.predict_loo(lo, hi, clean=clean_scores), dtype=np.float64)   # one device -> host copy per block
+            for r in range(hi - lo):
+                i = lo + r
+                head = f'{i + 1}{delimiter}"{sources[i]}"{delimiter}'
+                yrow, srow = y.array[i], scores[r]
+                f.write("".join(head + quoted_t[c] + delimiter + _julia_number(srow[c]) + delimiter + show_y(yrow[c]) + "\n"
+                                for c in range(len(targets))))
+                lines += len(targets)
+    if graph is None:
+        g.close()
+    return lines
 
 
 # --------------------------------------------------------------------------- text I/O (SURVEY 8f rank 4)

@@ -376,6 +376,36 @@ def test_loo_through_the_mirror_equals_fold_loop():
         assert_close(fast[i:i + 1], yh.array, np.float64)
 
 
+def test_save_loo_streams_the_reference_fold_loop_output(tmp_path):
+    """save_loo: every LOO fold scored from one resident graph, block by block, and appended in save's wire format
+    (src/core.jl:542-561) -- the file must be what the reference's user loop writes fold by fold (construct ->
+    predict -> clean! -> save), compared field by field (same text for names, fold ids and labels; scores to 1e-12)."""
+    rng = np.random.default_rng(9)
+    n, nt = 23, 4
+    S = rng.random((n, n)); S = (S + S.T) / 2; np.fill_diagonal(S, 1.0)
+    nm = [f"d{i:02d}" for i in range(n)]; tn = [f"t{i}" for i in range(nt)]
+    Y = (rng.random((n, nt)) < 0.3).astype(np.int64)
+    Y[:, 3] = 0; Y[4, 3] = 1                                  # a target whose only edge is one query: -99.0 in its fold
+    y = ss.NamedMatrix(Y, nm, tn)                             # integer payload: labels print bare, like test/data/save1-4
+    X = ss.featurize(ss.NamedMatrix(S, nm, nm), 0.5, True)
+    fast, slow = tmp_path / "fast.tsv", tmp_path / "slow.tsv"
+    assert ss.save_loo(str(fast), y, X, block=7) == n * nt    # 4 blocks, the last one short
+    for i, s in enumerate(nm, start=1):
+        A, B = ss.construct(y, X, [s])
+        yq = y.sub([s], tn)
+        yh = ss.predict((A, B), yq)
+        ss.clean(yh, A, yq)
+        ss.save(str(slow), i, yh, yq)
+    a = [ln.split("\t") for ln in fast.read_text().splitlines()]
+    b = [ln.split("\t") for ln in slow.read_text().splitlines()]
+    assert len(a) == len(b) == n * nt
+    for la, lb in zip(a, b):
+        assert la[:3] == lb[:3] and la[4] == lb[4], (la, lb)
+        assert abs(float(la[3]) - float(lb[3])) <= 1e-12 * max(1.0, abs(float(lb[3])))
+    assert any(l[3] == "-99.0" for l in a) and a[0][0] == "1" and a[-1][0] == str(n)
+    assert all("." in l[3] and "." not in l[4] for l in a)    # Float64 scores, bare Int labels
+
+
 # ----------------------------------------------------------------------------- raw W*R SpMM
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("B", [1, 2, 3, 4, 7, 8, 12, 16, 32, 33, 64, 65, 200])
