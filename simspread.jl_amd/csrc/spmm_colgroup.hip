@@ -45,7 +45,6 @@ struct ColArgs {
   T* P;        // [CG][M][BV] partial sums when CG > 1
   int rows_per_wg, RBn, CG, np_used;
   int vec_ok;
-  int dbg;  // SS_COL_DBG ablations (timing experiments only; results are wrong): 1 no tile staging, 2 no gathers
 };
 
 __device__ __attribute__((aligned(16))) unsigned int col_zero[4] = {0u, 0u, 0u, 0u};
@@ -182,8 +181,7 @@ __global__ void __launch_bounds__(WAVES * 64) spmm_colgroup_kernel(ColArgs<T> a)
     // LDS-DMA: a wave instruction fills 64 consecutive pieces of the tile; pieces outside R read a zero word
     const unsigned char* rbase = reinterpret_cast<const unsigned char*>(a.R + k0 * a.ldr);
     const int64_t rowstride = a.ldr * (int64_t)sizeof(T);
-    if (a.dbg & 1) {
-    } else if (a.vec_ok) {
+    if (a.vec_ok) {
       const int pieces = (a.KC + 1) * NCG;
       const int bslots = a.B / PW;
       for (int base = (tid >> 6) * 64; base < pieces; base += COL_THREADS) {
@@ -216,7 +214,6 @@ __global__ void __launch_bounds__(WAVES * 64) spmm_colgroup_kernel(ColArgs<T> a)
     // No memory loads in here: the waits for the prefetched quads stay counted (a load inside would turn them into
     // vmcnt(0)).
     auto batch = [&](int p, int nq, const uint2 iv, const Q w) __attribute__((always_inline)) {
-      if (a.dbg & 2) { acc[p][0] += __uint_as_float(iv.x) + (BIN ? T(0) : w.v[0]); nq = 0; }
 #define SS_COL_QUAD(E, CTRL)                                                                      \
       if (E < nq) {                                                                               \
         const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)iv.x, CTRL, 0xF, 0xF, true);   \
@@ -331,13 +328,14 @@ static int launch_col_variant(const ColArgs<T>& a, unsigned grid, size_t lds) {
   return SS_OK;
 }
 
-// Waves per workgroup and row sets per wave (16 rows each).  Rows per workgroup = WAVES * NP * 16 = 2048 (64- and
-// 128-byte tile rows) or 1280 (256-byte rows): NP * ROWB/16 accumulator registers per lane next to the quads in flight,
-// the gathered tile rows and addresses.  16 waves (128 registers each) hide the latencies better (measured, B = 16
-// binary: 0.22 ms vs 0.29 ms with 8 waves) where the accumulators fit.
-constexpr int col_waves(int rowb) { return rowb == 256 ? 8 : 16; }
+// Waves per workgroup and row sets per wave (16 rows each).  Rows per workgroup = WAVES * NP * 16 = 2048 (64-byte tile
+// rows: 16 waves x 8), 2112 (128-byte rows: 12 waves x 11) or 1280 (256-byte rows: 8 waves x 10): NP * ROWB/16
+// accumulator registers per lane next to the quads in flight, the gathered tile rows and addresses, inside the
+// 128 / 168 / 256 registers a lane may use at 16 / 12 / 8 waves per CU.  More waves hide the latencies better
+// (measured, B = 16 pattern-only: 0.22 ms with 16 waves vs 0.29 ms with 8) where the accumulators fit.
+constexpr int col_waves(int rowb) { return rowb == 256 ? 8 : (rowb == 128 ? 12 : 16); }
 constexpr int col_np(int rowb, bool bin = true, int elem = 4) {
-  return rowb == 256 ? ((!bin && elem == 8) ? 8 : 10) : 8;
+  return rowb == 256 ? ((!bin && elem == 8) ? 8 : 10) : (rowb == 128 ? 11 : 8);
 }
 constexpr int col_max_rows(int rowb) { return col_waves(rowb) * col_np(rowb) * COL_ROWS; }
 
@@ -371,7 +369,6 @@ int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr
   a.M = W.rows; a.K = W.cols; a.KC = W.SC; a.nchunks = W.nchunks; a.B = B;
   a.R = R; a.ldr = ldr; a.F = F; a.ldf = ldf;
   constexpr int PW = 16 / (int)sizeof(T);
-  a.dbg = getenv("SS_COL_DBG") ? atoi(getenv("SS_COL_DBG")) : 0;
   a.vec_ok = (ldr % PW == 0 && B % PW == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0) ? 1 : 0;
 
   // the cut: RB row blocks x CG chunk groups.  A workgroup holds 8 waves * NP * 16 rows (accumulators in registers);
