@@ -150,11 +150,16 @@ int ss_graph_create_dense_f64(int64_t nq, int64_t ns, int64_t nf, int64_t nt,
  * Sq (nq x ns) and Ss (ns x ns) are column-major raw similarities whose columns are the features named
  * after the sources; nq may be 0.  Serves ss_predict_f32 (query and source rows), ss_predict_loo_f32 and
  * ss_predict_kfold_f32.
- * fp32 only (the exact-fp32 matrix instruction); there is no _f64 form. */
+ * _f32: bf16 matrix cores on exact bf16 planes (the reference's GPU=true precision, src/core.jl:404); _f64: the fp64
+ * matrix instruction (the reference's default precision, src/core.jl:402 GPU=false). */
 int ss_graph_create_similarity_f32(int64_t nq, int64_t ns, int64_t nt,
                                    const float* Sq, int64_t ldq, const float* Ss, int64_t lds,
                                    const int64_t* y_ptr, const int32_t* y_idx, const float* y_val,
                                    int index_base, float alpha, int weighted, int mem, ss_graph** out);
+int ss_graph_create_similarity_f64(int64_t nq, int64_t ns, int64_t nt,
+                                   const double* Sq, int64_t ldq, const double* Ss, int64_t lds,
+                                   const int64_t* y_ptr, const int32_t* y_idx, const double* y_val,
+                                   int index_base, double alpha, int weighted, int mem, ss_graph** out);
 /* General form for caller-built adjacency matrices: predict accepts ANY named A, B
  * (src/core.jl:402-425; the reference's own test passes hand-written 9 x 9 matrices,
  * test/runtests.jl:120-158).  With n nodes, the caller passes

@@ -208,21 +208,30 @@ end
     graph_similarity(Sq, Ss, Y::SparseMatrixCSC; alpha, weighted=true)
 
 Dense-similarity regime (thresholded similarity too full for CSR): raw similarities `Sq` (nq x ns, or `nothing`) and
-`Ss` (ns x ns) stay dense on the device, featurize's cutoff is applied inside the matrix-core product; fp32 only.
+`Ss` (ns x ns) stay dense on the device, featurize's cutoff is applied inside the matrix-core product
+(`T=Float32`: bf16 planes, `T=Float64`: the fp64 matrix instruction).
 """
 function graph_similarity(Sq::Union{Nothing,AbstractMatrix}, Ss::AbstractMatrix, Y::SparseMatrixCSC;
-                          alpha::Real, weighted::Bool=true)
+                          alpha::Real, weighted::Bool=true, T::Type=Float32)
     ns = size(Ss, 1)
-    q = Sq === nothing ? Matrix{Float32}(undef, 0, ns) : Matrix{Float32}(Sq)
-    s = Matrix{Float32}(Ss)
-    yp, yi, yv = _csr(Y, Float32)
+    q = Sq === nothing ? Matrix{T}(undef, 0, ns) : Matrix{T}(Sq)
+    s = Matrix{T}(Ss)
+    yp, yi, yv = _csr(Y, T)
     nq, nt = size(q, 1), size(Y, 2)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:ss_graph_create_similarity_f32, LIB), Cint,
-                (Int64, Int64, Int64, Ptr{Float32}, Int64, Ptr{Float32}, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float32},
-                 Cint, Float32, Cint, Cint, Ref{Ptr{Cvoid}}),
-                nq, ns, nt, q, max(nq, 1), s, max(ns, 1), yp, yi, yv, 1, Float32(alpha), weighted ? 1 : 0, SS_MEM_HOST, h))
-    return Graph{Float32}(h[], nq, ns, ns, nt)
+    rc = if T === Float32
+        ccall((:ss_graph_create_similarity_f32, LIB), Cint,
+              (Int64, Int64, Int64, Ptr{Float32}, Int64, Ptr{Float32}, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float32},
+               Cint, Float32, Cint, Cint, Ref{Ptr{Cvoid}}),
+              nq, ns, nt, q, max(nq, 1), s, max(ns, 1), yp, yi, yv, 1, Float32(alpha), weighted ? 1 : 0, SS_MEM_HOST, h)
+    else
+        ccall((:ss_graph_create_similarity_f64, LIB), Cint,
+              (Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float64},
+               Cint, Float64, Cint, Cint, Ref{Ptr{Cvoid}}),
+              nq, ns, nt, q, max(nq, 1), s, max(ns, 1), yp, yi, yv, 1, Float64(alpha), weighted ? 1 : 0, SS_MEM_HOST, h)
+    end
+    check(rc)
+    return Graph{T}(h[], nq, ns, ns, nt)
 end
 
 """

@@ -58,6 +58,7 @@ def _sigs():
     s["ss_topl_f32"] = ([_vp, _i64, _i64, _i64, _int, _vp, _vp, _int], _int)
     s["ss_rank_metrics_f32"] = ([_vp, _vp, _i64, f64, _vp, _int], _int)
     s["ss_graph_create_similarity_f32"] = ([_i64] * 3 + [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _int, f32, _int, _int, _vp], _int)
+    s["ss_graph_create_similarity_f64"] = ([_i64] * 3 + [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _int, f64, _int, _int, _vp], _int)
     for suf, ft in (("f32", f32), ("f64", f64)):
         s[f"ss_cutoff_{suf}"] = ([_vp, _i64, _i64, _i64, ft, _int, _vp, _i64, _int], _int)
         s[f"ss_similarity_jaccard_{suf}"] = ([_vp, _i64, _i64, _i64, _vp, _i64, _int], _int)

@@ -291,10 +291,11 @@ static int graph_create_general_impl(int64_t n, int64_t nr, int64_t nc, const in
   return SS_OK;
 }
 
-// dense-similarity graph (fp32): raw similarities resident, labels sparse
-static int graph_create_similarity_impl(int64_t nq, int64_t ns, int64_t nt, const float* Sq, int64_t ldq,
-                                        const float* Ss, int64_t lds, const int64_t* y_ptr, const int32_t* y_idx,
-                                        const float* y_val, int index_base, float alpha, int weighted, int mem,
+// dense-similarity graph: raw similarities resident, labels sparse
+template <class T>
+static int graph_create_similarity_impl(int64_t nq, int64_t ns, int64_t nt, const T* Sq, int64_t ldq,
+                                        const T* Ss, int64_t lds, const int64_t* y_ptr, const int32_t* y_idx,
+                                        const T* y_val, int index_base, T alpha, int weighted, int mem,
                                         ss_graph** out) {
   SS_TRY(require_init());
   SS_TRY(check_mem(mem));
@@ -303,24 +304,24 @@ static int graph_create_similarity_impl(int64_t nq, int64_t ns, int64_t nt, cons
   if (nq < 0 || ns < 0 || nt < 0) return fail(SS_EINVAL, "negative node count");
   if ((nq > 0 && (!Sq || ldq < nq)) || (ns > 0 && (!Ss || lds < ns)))
     return fail(SS_EINVAL, "similarity block: NULL pointer or ld < rows");
-  GraphBox<float>* box = new (std::nothrow) GraphBox<float>();
+  GraphBox<T>* box = new (std::nothrow) GraphBox<T>();
   if (!box) return fail(SS_ENOMEM, "host allocation failed");
-  box->dtype = 4;
-  Graph<float>& g = box->g;
+  box->dtype = (int)sizeof(T);
+  Graph<T>& g = box->g;
   g.nq = nq; g.ns = ns; g.nf = ns; g.nt = nt;
-  DenseSim<float>& d = g.dense;
+  DenseSim<T>& d = g.dense;
   d.on = true; d.nq = nq; d.ns = ns; d.nf = ns; d.alpha = alpha; d.weighted = weighted != 0;
   hipStream_t st = ctx().stream;
-  auto stage = [&](const float* src, int64_t rows, int64_t ld, DevBuf<float>& dst) -> int {
+  auto stage = [&](const T* src, int64_t rows, int64_t ld, DevBuf<T>& dst) -> int {
     SS_TRY(dst.alloc((size_t)rows * (size_t)ns));
     if (rows == 0 || ns == 0) return SS_OK;
-    SS_HIP(hipMemcpy2DAsync(dst.p, rows * sizeof(float), src, ld * sizeof(float), rows * sizeof(float), ns,
+    SS_HIP(hipMemcpy2DAsync(dst.p, rows * sizeof(T), src, ld * sizeof(T), rows * sizeof(T), ns,
                             mem == SS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
     return SS_OK;
   };
   int rc = stage(Sq, nq, ldq, d.Sq);
   if (rc == SS_OK) rc = stage(Ss, ns, lds, d.Ss);
-  if (rc == SS_OK) rc = csr_from_user<float>(ns, nt, y_ptr, y_idx, y_val, index_base, mem, g.Ys);
+  if (rc == SS_OK) rc = csr_from_user<T>(ns, nt, y_ptr, y_idx, y_val, index_base, mem, g.Ys);
   if (rc == SS_OK) rc = csr_transpose(g.Ys, g.YsT);
   if (rc == SS_OK) rc = graph_finalize_general_targets(g);
   if (rc == SS_OK) rc = dense_degrees(g);
@@ -415,18 +416,24 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
     {
       StageTimer t1(ST_TRANSFER);
       if (g.dense.on) {
-        if constexpr (std::is_same<T, float>::value) {
+        {
           const bool loo = (kind == 2);
           const bool srcrows = (kind == SS_ROWS_SOURCE);  // feature path here, target path added below
-          // default: bf16 matrix cores on exact bf16 planes of the operands (dense_bf16.hip: 1.5x weighted, 3.2x
-          // unweighted at 50k); SS_DENSE_BF16=0: the fp32-input MFMA kernel of dense.hip
-          const bool use_bf16 = !(getenv("SS_DENSE_BF16") && atoi(getenv("SS_DENSE_BF16")) == 0);
-          if (use_bf16)
-            SS_TRY(launch_transfer_dense_bf16(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
-                                              row_begin + r0, nb, Tbuf.p, nj, srcrows));
-          else
-            SS_TRY(launch_transfer_dense(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
-                                         row_begin + r0, nb, Tbuf.p, nj, srcrows));
+          if constexpr (std::is_same<T, float>::value) {
+            // default: bf16 matrix cores on exact bf16 planes of the operands (dense_bf16.hip: 1.5x weighted, 3.2x
+            // unweighted at 50k); SS_DENSE_BF16=0: the fp32-input MFMA kernel of dense.hip
+            const bool use_bf16 = !(getenv("SS_DENSE_BF16") && atoi(getenv("SS_DENSE_BF16")) == 0);
+            if (use_bf16)
+              SS_TRY(launch_transfer_dense_bf16(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
+                                                row_begin + r0, nb, Tbuf.p, nj, srcrows));
+            else
+              SS_TRY(launch_transfer_dense(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
+                                           row_begin + r0, nb, Tbuf.p, nj, srcrows));
+          } else {
+            // fp64 (the reference's default precision): the fp64 matrix instruction, dense_f64.hip
+            SS_TRY(launch_transfer_dense_f64(g.dense, loo, loo ? g.dense.inv_kf_m1.p : g.inv_kf.p, g.inv_ks.p, g.ks.p,
+                                             row_begin + r0, nb, Tbuf.p, nj, srcrows));
+          }
           if (srcrows) {
             // target path (Ys D_t^-1) Ys' D_s^-1 of the source rows: sparse, added to T
             const DevCsr<T>* L[2] = {&g.Ys, nullptr};
@@ -434,8 +441,6 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
             const T* inv1[2] = {g.inv_kt.p, nullptr};
             SS_TRY(launch_transfer<T>(1, L, inv1, M, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj, nullptr, true));
           }
-        } else {
-          return fail(SS_EUNSUPPORTED, "the dense-similarity path is fp32 only");
         }
       } else if (kind == 2) {
         SS_TRY(launch_transfer_loo<T>(g.Xs, g.XsTc, g.kf.p, g.ks.p, row_begin + r0, nb, Tbuf.p, nj));
@@ -619,8 +624,7 @@ static int predict_kfold_impl(ss_graph* h, const int32_t* fold_of_source, int nf
     SS_HIP(hipMemcpyAsync(ks.p, g.ks.p, ns * sizeof(int), hipMemcpyDeviceToDevice, st));
     SS_HIP(hipMemcpyAsync(kt.p, g.kt.p, nt * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (g.dense.on) {
-      if constexpr (std::is_same<T, float>::value) SS_TRY(dense_fold_degrees(g, members, nm, kf.p, ks.p, kt.p));
-      else return fail(SS_EUNSUPPORTED, "the dense-similarity path is fp32 only");
+      SS_TRY(dense_fold_degrees<T>(g, members, nm, kf.p, ks.p, kt.p));
     } else {
       SS_TRY(launch_fold_degrees<T>(g.Xs, g.XsT, g.Ys, members, nm, kf.p, ks.p, kt.p));
     }
@@ -638,6 +642,9 @@ static int predict_kfold_impl(ss_graph* h, const int32_t* fold_of_source, int nf
           if constexpr (std::is_same<T, float>::value)
             SS_TRY(launch_transfer_dense_bf16(g.dense, false, inv_kf.p, inv_ks.p, nullptr, r0, nb, g.Tws.p, ns, false,
                                               members));
+          else
+            SS_TRY(launch_transfer_dense_f64(g.dense, false, inv_kf.p, inv_ks.p, nullptr, r0, nb, g.Tws.p, ns, false,
+                                             members));
         } else {
           const DevCsr<T>* L[2] = {&g.Xs, nullptr};
           const DevChunked<T>* M[2] = {&g.XsTc, nullptr};
@@ -1182,8 +1189,15 @@ int ss_graph_create_similarity_f32(int64_t nq, int64_t ns, int64_t nt, const flo
                                    int64_t lds, const int64_t* y_ptr, const int32_t* y_idx, const float* y_val,
                                    int index_base, float alpha, int weighted, int mem, ss_graph** out) {
   SS_API_LOCK();
-  return graph_create_similarity_impl(nq, ns, nt, Sq, ldq, Ss, lds, y_ptr, y_idx, y_val, index_base, alpha, weighted,
-                                      mem, out);
+  return graph_create_similarity_impl<float>(nq, ns, nt, Sq, ldq, Ss, lds, y_ptr, y_idx, y_val, index_base, alpha,
+                                             weighted, mem, out);
+}
+int ss_graph_create_similarity_f64(int64_t nq, int64_t ns, int64_t nt, const double* Sq, int64_t ldq, const double* Ss,
+                                   int64_t lds, const int64_t* y_ptr, const int32_t* y_idx, const double* y_val,
+                                   int index_base, double alpha, int weighted, int mem, ss_graph** out) {
+  SS_API_LOCK();
+  return graph_create_similarity_impl<double>(nq, ns, nt, Sq, ldq, Ss, lds, y_ptr, y_idx, y_val, index_base, alpha,
+                                              weighted, mem, out);
 }
 
 int ss_graph_destroy(ss_graph* h) {

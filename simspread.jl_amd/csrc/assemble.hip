@@ -974,12 +974,13 @@ int graph_finalize_general(Graph<T>& g) {
   return SS_OK;
 }
 
-int graph_finalize_general_targets(Graph<float>& g) {
+template <class T>
+int graph_finalize_general_targets(Graph<T>& g) {
   hipStream_t st = ctx().stream;
   SS_TRY(g.kt.alloc(g.nt));
   SS_TRY(g.inv_kt.alloc(g.nt));
   if (g.nt > 0) {
-    hipLaunchKernelGGL(degree_kernel<float>, dim3(grid_for(g.nt, 256)), dim3(256), 0, st, g.YsT.ptr.p,
+    hipLaunchKernelGGL(degree_kernel<T>, dim3(grid_for(g.nt, 256)), dim3(256), 0, st, g.YsT.ptr.p,
                        (const int*)nullptr, g.nt, g.kt.p, g.inv_kt.p);
     SS_LAUNCH_CHECK();
   }
@@ -988,6 +989,7 @@ int graph_finalize_general_targets(Graph<float>& g) {
 }
 
 #define SS_INSTANTIATE(T)                                                                                      \
+  template int graph_finalize_general_targets<T>(Graph<T>&);                                                    \
   template int csr_from_user<T>(int64_t, int64_t, const int64_t*, const int32_t*, const T*, int, int, DevCsr<T>&); \
   template int csr_from_dense<T>(const T*, int64_t, int64_t, int64_t, bool, T, bool, int, DevCsr<T>&);         \
   template int csr_transpose<T>(const DevCsr<T>&, DevCsr<T>&);                                                 \

@@ -17,35 +17,38 @@ namespace ss {
       return fail(SS_EHIP, "%s:%d kernel launch: %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
   } while (0)
 
-__device__ __forceinline__ float cut_val(float x, float alpha, int weighted) {
+template <class T>
+__device__ __forceinline__ T cut_val(T x, T alpha, int weighted) {
   // cutoff(x, alpha, weighted); a kept weight of 0 is no edge
-  return (x >= alpha) ? (weighted ? x : 1.0f) : 0.0f;
+  return (x >= alpha) ? (weighted ? x : T(1)) : T(0);
 }
 
 // ------------------------------------------------------------------ degrees of the thresholded similarity
 // kf[f] = #rows with cut(S[row,f]) != 0: one wave per column (contiguous in column-major)
-__global__ void dense_col_degree_kernel(const float* __restrict__ S, int64_t rows, int64_t cols, int64_t ld,
-                                        float alpha, int weighted, int* __restrict__ deg) {
+template <class T>
+__global__ void dense_col_degree_kernel(const T* __restrict__ S, int64_t rows, int64_t cols, int64_t ld,
+                                        T alpha, int weighted, int* __restrict__ deg) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t f = wave0; f < cols; f += nwaves) {
     int n = 0;
-    for (int64_t r = lane; r < rows; r += 64) n += cut_val(S[r + f * ld], alpha, weighted) != 0.0f ? 1 : 0;
+    for (int64_t r = lane; r < rows; r += 64) n += cut_val(S[r + f * ld], alpha, weighted) != T(0) ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
     if (lane == 0) deg[f] = n;
   }
 }
 
 // row counts: thread per row, lanes walk a column together; column splits add with integer atomics
-__global__ void dense_row_degree_kernel(const float* __restrict__ S, int64_t rows, int64_t cols, int64_t ld,
-                                        float alpha, int weighted, int64_t cols_per_split, int* __restrict__ deg) {
+template <class T>
+__global__ void dense_row_degree_kernel(const T* __restrict__ S, int64_t rows, int64_t cols, int64_t ld,
+                                        T alpha, int weighted, int64_t cols_per_split, int* __restrict__ deg) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   const int64_t c0 = (int64_t)blockIdx.y * cols_per_split;
   const int64_t c1 = (c0 + cols_per_split < cols) ? c0 + cols_per_split : cols;
   int n = 0;
-  for (int64_t c = c0; c < c1; ++c) n += cut_val(S[r + c * ld], alpha, weighted) != 0.0f ? 1 : 0;
+  for (int64_t c = c0; c < c1; ++c) n += cut_val(S[r + c * ld], alpha, weighted) != T(0) ? 1 : 0;
   atomicAdd(&deg[r], n);
 }
 
@@ -280,23 +283,25 @@ int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k
 // kf[f] -= #{members m : cut(S[m,f]) != 0} (one wave per feature column, lanes walk the members),
 // ks[s] -= #{member features m : cut(S[s,m]) != 0} (thread per source row, coalesced along the column),
 // kt[t] -= #{members m : Y[m,t] != 0} (CSR rows of the members).
-__global__ void dense_fold_kf_kernel(const float* __restrict__ S, int64_t ld, int64_t nf, float alpha, int weighted,
+template <class T>
+__global__ void dense_fold_kf_kernel(const T* __restrict__ S, int64_t ld, int64_t nf, T alpha, int weighted,
                                      const int* __restrict__ members, int64_t nm, int* __restrict__ kf) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t f = wave0; f < nf; f += nwaves) {
     int n = 0;
-    for (int64_t i = lane; i < nm; i += 64) n += cut_val(S[members[i] + f * ld], alpha, weighted) != 0.0f ? 1 : 0;
+    for (int64_t i = lane; i < nm; i += 64) n += cut_val(S[members[i] + f * ld], alpha, weighted) != T(0) ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
     if (lane == 0) kf[f] -= n;
   }
 }
-__global__ void dense_fold_ks_kernel(const float* __restrict__ S, int64_t ld, int64_t ns, float alpha, int weighted,
+template <class T>
+__global__ void dense_fold_ks_kernel(const T* __restrict__ S, int64_t ld, int64_t ns, T alpha, int weighted,
                                      const int* __restrict__ members, int64_t nm, int* __restrict__ ks) {
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += (int64_t)gridDim.x * blockDim.x) {
     int n = 0;
-    for (int64_t i = 0; i < nm; ++i) n += cut_val(S[s + (int64_t)members[i] * ld], alpha, weighted) != 0.0f ? 1 : 0;
+    for (int64_t i = 0; i < nm; ++i) n += cut_val(S[s + (int64_t)members[i] * ld], alpha, weighted) != T(0) ? 1 : 0;
     ks[s] -= n;
   }
 }
@@ -311,15 +316,16 @@ __global__ void dense_fold_kt_kernel(const int* __restrict__ yptr, const int* __
   }
 }
 
-int dense_fold_degrees(const Graph<float>& g, const int* members, int64_t nm, int* kf, int* ks, int* kt) {
+template <class T>
+int dense_fold_degrees(const Graph<T>& g, const int* members, int64_t nm, int* kf, int* ks, int* kt) {
   if (nm <= 0) return SS_OK;
-  const DenseSim<float>& d = g.dense;
+  const DenseSim<T>& d = g.dense;
   hipStream_t st = ctx().stream;
   const auto cap = [](int64_t x) { return (unsigned)(x < 1 ? 1 : (x > 4096 ? 4096 : x)); };
-  hipLaunchKernelGGL(dense_fold_kf_kernel, dim3(cap(ceil_div(d.nf * 64, 256))), dim3(256), 0, st, d.Ss.p, d.ns, d.nf,
+  hipLaunchKernelGGL(dense_fold_kf_kernel<T>, dim3(cap(ceil_div(d.nf * 64, 256))), dim3(256), 0, st, d.Ss.p, d.ns, d.nf,
                      d.alpha, d.weighted ? 1 : 0, members, nm, kf);
   SS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dense_fold_ks_kernel, dim3(cap(ceil_div(d.ns, 256))), dim3(256), 0, st, d.Ss.p, d.ns, d.ns, d.alpha,
+  hipLaunchKernelGGL(dense_fold_ks_kernel<T>, dim3(cap(ceil_div(d.ns, 256))), dim3(256), 0, st, d.Ss.p, d.ns, d.ns, d.alpha,
                      d.weighted ? 1 : 0, members, nm, ks);
   SS_LAUNCH_CHECK();
   hipLaunchKernelGGL(dense_fold_kt_kernel, dim3(cap(ceil_div(nm * 64, 256))), dim3(256), 0, st, g.Ys.ptr.p, g.Ys.idx.p,
@@ -329,9 +335,10 @@ int dense_fold_degrees(const Graph<float>& g, const int* members, int64_t nm, in
 }
 
 // degrees of the thresholded similarity + labels: kf (columns of cut(Ss)), ks (rows of cut(Ss) + rows of Y)
-int dense_degrees(Graph<float>& g) {
+template <class T>
+int dense_degrees(Graph<T>& g) {
   hipStream_t st = ctx().stream;
-  DenseSim<float>& d = g.dense;
+  DenseSim<T>& d = g.dense;
   DevBuf<int> kx;
   SS_TRY(kx.alloc(d.ns));
   SS_TRY(g.kf.alloc(d.nf));
@@ -342,7 +349,7 @@ int dense_degrees(Graph<float>& g) {
   if (d.ns > 0 && d.nf > 0) {
     DevBuf<int> kcol;
     SS_TRY(kcol.alloc(d.nf));
-    hipLaunchKernelGGL(dense_col_degree_kernel, dim3((unsigned)(ceil_div(d.nf * 64, 256) < 4096 ? ceil_div(d.nf * 64, 256) : 4096)),
+    hipLaunchKernelGGL(dense_col_degree_kernel<T>, dim3((unsigned)(ceil_div(d.nf * 64, 256) < 4096 ? ceil_div(d.nf * 64, 256) : 4096)),
                        dim3(256), 0, st, d.Ss.p, d.ns, d.nf, d.ns, d.alpha, d.weighted ? 1 : 0, kcol.p);
     SS_LAUNCH_CHECK();
     SS_HIP(hipMemsetAsync(kx.p, 0, d.ns * sizeof(int), st));
@@ -352,18 +359,23 @@ int dense_degrees(Graph<float>& g) {
     if (nsplit > 1024) nsplit = 1024;
     const int64_t cps = ceil_div(d.nf, nsplit);
     nsplit = (int)ceil_div(d.nf, cps);
-    hipLaunchKernelGGL(dense_row_degree_kernel, dim3((unsigned)ceil_div(d.ns, 64), (unsigned)nsplit), dim3(64), 0, st,
+    hipLaunchKernelGGL(dense_row_degree_kernel<T>, dim3((unsigned)ceil_div(d.ns, 64), (unsigned)nsplit), dim3(64), 0, st,
                        d.Ss.p, d.ns, d.nf, d.ns, d.alpha, d.weighted ? 1 : 0, cps, kx.p);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dense_finish_degrees_kernel<float>, dim3((unsigned)ceil_div(d.nf, 256)), dim3(256), 0, st, kcol.p,
+    hipLaunchKernelGGL(dense_finish_degrees_kernel<T>, dim3((unsigned)ceil_div(d.nf, 256)), dim3(256), 0, st, kcol.p,
                        (const int*)nullptr, d.nf, g.kf.p, g.inv_kf.p, d.inv_kf_m1.p);
     SS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dense_finish_degrees_kernel<float>, dim3((unsigned)ceil_div(d.ns, 256)), dim3(256), 0, st, kx.p,
-                       g.Ys.ptr.p, d.ns, g.ks.p, g.inv_ks.p, (float*)nullptr);
+    hipLaunchKernelGGL(dense_finish_degrees_kernel<T>, dim3((unsigned)ceil_div(d.ns, 256)), dim3(256), 0, st, kx.p,
+                       g.Ys.ptr.p, d.ns, g.ks.p, g.inv_ks.p, (T*)nullptr);
     SS_LAUNCH_CHECK();
   }
   SS_HIP(hipStreamSynchronize(st));
   return SS_OK;
 }
+
+template int dense_degrees<float>(Graph<float>&);
+template int dense_degrees<double>(Graph<double>&);
+template int dense_fold_degrees<float>(const Graph<float>&, const int*, int64_t, int*, int*, int*);
+template int dense_fold_degrees<double>(const Graph<double>&, const int*, int64_t, int*, int*, int*);
 
 }  // namespace ss

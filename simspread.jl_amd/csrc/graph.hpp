@@ -134,7 +134,8 @@ template <class T>
 int graph_finalize(Graph<T>& g);  // transposes + degrees
 template <class T>
 int graph_finalize_general(Graph<T>& g);  // degrees = row counts of B (held in XsT)
-int graph_finalize_general_targets(Graph<float>& g);  // kt / inv_kt from YsT only
+template <class T>
+int graph_finalize_general_targets(Graph<T>& g);  // kt / inv_kt from YsT only
 
 // ---- kernels.hip (launch wrappers; everything is enqueued on ctx().stream)
 template <class T>
@@ -216,12 +217,18 @@ int launch_rank_metrics(const unsigned char* y, const float* yhat, int64_t n, do
 // ---- dense.hip (fp32 only: fp32-input MFMA)
 int launch_transfer_dense(const DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
                           int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows = false);
-int dense_degrees(Graph<float>& g);
+template <class T>
+int dense_degrees(Graph<T>& g);
 // dense_bf16.hip: the same product on the bf16 matrix cores with the operands split into exact bf16 planes
 int launch_transfer_dense_bf16(DenseSim<float>& d, bool loo, const float* inv_k, const float* inv_n, const int* ks,
                                int64_t row_begin, int64_t nrows, float* out, int64_t ldo, bool source_rows = false,
                                const int* row_ids = nullptr);
-int dense_fold_degrees(const Graph<float>& g, const int* members, int64_t nm, int* kf, int* ks, int* kt);
+template <class T>
+int dense_fold_degrees(const Graph<T>& g, const int* members, int64_t nm, int* kf, int* ks, int* kt);
+// dense_f64.hip: the dense-similarity stage 1 in fp64 (fp64 MFMA; the reference's default precision)
+int launch_transfer_dense_f64(const DenseSim<double>& d, bool loo, const double* inv_k, const double* inv_n, const int* ks,
+                              int64_t row_begin, int64_t nrows, double* out, int64_t ldo, bool source_rows = false,
+                              const int* row_ids = nullptr);
 
 template <class T>
 int launch_transpose(const T* in, int64_t rows, int64_t cols, int64_t ldin, T* out, int64_t ldout);

@@ -161,25 +161,30 @@ class DeviceGraph:
         return cls(h, dtype)
 
     @classmethod
-    def from_similarity(cls, Sq, Ss, Y, alpha: float, weighted: bool = True):
-        """Dense-similarity regime (fp32): raw similarities Sq (nq x ns, may be None) and Ss (ns x ns) stay dense
-        on the device, the cutoff is applied inside the MFMA stage-1 product; Y (ns x nt) is sparse.  Inputs:
-        numpy arrays / scipy matrix on the host, or torch CUDA tensors for Sq, Ss with Y = (ptr, idx, val) device
-        CSR.  Serves predict("query") and predict_loo()."""
+    def from_similarity(cls, Sq, Ss, Y, alpha: float, weighted: bool = True, dtype=np.float32):
+        """Dense-similarity regime: raw similarities Sq (nq x ns, may be None) and Ss (ns x ns) stay dense on the
+        device, the cutoff is applied inside the MFMA stage-1 product; Y (ns x nt) is sparse.  dtype float32: bf16
+        matrix cores on exact bf16 planes (the reference's GPU=true precision); float64: the fp64 matrix instruction
+        (the reference's default precision).  Inputs: numpy arrays / scipy matrix on the host, or torch CUDA tensors
+        for Sq, Ss with Y = (ptr, idx, val) device CSR.  Serves predict (query / source rows), predict_loo and
+        predict_kfold."""
         import scipy.sparse as sp
         lib = L.lib()
         dev = _is_torch(Ss)
         keep = []
+        dt = np.dtype(dtype).type
+        if dt not in (np.float32, np.float64):
+            raise TypeError("dtype must be float32 or float64")
 
         def dense_cm(a):
             if a is None:
                 return None, 1, 0
             if dev:
                 import torch
-                t = a.to(torch.float32).t().contiguous()   # row-major transpose == column-major original
+                t = a.to(torch.float32 if dt == np.float32 else torch.float64).t().contiguous()   # row-major transpose == column-major original
                 keep.append(t)
                 return t.data_ptr(), a.shape[0], a.shape[0]
-            arr = np.asfortranarray(np.asarray(a, dtype=np.float32))
+            arr = np.asfortranarray(np.asarray(a, dtype=dt))
             keep.append(arr)
             return arr.ctypes.data, max(arr.shape[0], 1), arr.shape[0]
 
@@ -195,17 +200,21 @@ class DeviceGraph:
             if Y.shape[0] != ns:
                 raise AssertionError("Labels and features have different number of source nodes")
             nt = Y.shape[1]
-            parts = _csr_parts(Y, np.float32)
+            parts = _csr_parts(Y, dt)
             keep.append(parts)
             yptr, yidx, yval = _ptr(parts[0]), _ptr(parts[1]), _ptr(parts[2])
             mem = L.SS_MEM_HOST
         h = C.c_void_p()
-        L.check(lib.ss_graph_create_similarity_f32(nq, ns, nt, pq, ldq, ps, lds, yptr, yidx, yval, 0,
-                                                   C.c_float(alpha), 1 if weighted else 0, mem, C.byref(h)))
+        if dt == np.float32:
+            L.check(lib.ss_graph_create_similarity_f32(nq, ns, nt, pq, ldq, ps, lds, yptr, yidx, yval, 0,
+                                                       C.c_float(alpha), 1 if weighted else 0, mem, C.byref(h)))
+        else:
+            L.check(lib.ss_graph_create_similarity_f64(nq, ns, nt, pq, ldq, ps, lds, yptr, yidx, yval, 0,
+                                                       C.c_double(alpha), 1 if weighted else 0, mem, C.byref(h)))
         if dev:
             L.check(lib.ss_synchronize())
         del keep
-        return cls(h, np.float32)
+        return cls(h, dt)
 
     @classmethod
     def general(cls, A_rows, B, B_cols_T, dtype=np.float64):

@@ -594,6 +594,36 @@ def test_dense_similarity_path_query_and_loo(shape, weighted, engine, monkeypatc
     assert_close(g.predict("source", lo, hi, clean=True), gs.predict("source", lo, hi, clean=True), np.float32)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("shape", [(70, 333, 41), (1, 64, 5), (130, 257, 300)])
+def test_dense_similarity_path_fp64(shape, weighted):
+    """The dense-similarity regime in the reference's default precision (Float64, src/core.jl:402 GPU=false): fp64 matrix
+    instruction (dense_f64.hip), cutoff fused into the operand staging -- query rows, source rows, leave-one-out (rank-1
+    degree corrections) and k-fold (member rows gathered, per-fold degrees), all to 1e-12."""
+    nq, ns, nt = shape
+    rng = np.random.default_rng(ns + 1)
+    Ss = rng.random((ns, ns)); Ss = (Ss + Ss.T) / 2; np.fill_diagonal(Ss, 1.0)
+    Sq = rng.random((nq, ns))
+    Y = sp.random(ns, nt, density=0.08, format="csr", random_state=rng, dtype=np.float64); Y.data[:] = 1.0
+    alpha = 0.35
+    Ss[3, 7] = Ss[7, 3] = alpha  # exactly alpha: kept
+    g = ss.DeviceGraph.from_similarity(Sq, Ss, Y, alpha=alpha, weighted=weighted, dtype=np.float64)
+    Xq, Xs = O.cutoff(Sq, alpha, weighted), O.cutoff(Ss, alpha, weighted)
+    kf, ks, kt = g.degrees()
+    okf, oks, okt = O.degrees(Xs, Y)
+    np.testing.assert_array_equal(kf, okf); np.testing.assert_array_equal(ks, oks); np.testing.assert_array_equal(kt, okt)
+    assert_close(g.predict("query"), O.predict_factored(Xq, Xs, Y), np.float64)
+    assert "transfer_dense_f64_mfma" in ss.path_last()
+    want = O.predict_loo_factored(Xs, Y, clean_flag=True)
+    assert_close(g.predict_loo(clean=True), want, np.float64)
+    lo, hi = ns // 3, ns - 1
+    assert_close(g.predict_loo(lo, hi, clean=True, layout="col"), want[lo:hi], np.float64)
+    gs = ss.DeviceGraph.from_dense(None, Ss, Y.toarray(), alpha=alpha, weighted=weighted, dtype=np.float64)
+    assert_close(g.predict("source"), gs.predict("source"), np.float64)
+    folds = rng.integers(0, 4, ns).astype(np.int32)
+    assert_close(g.predict_kfold(folds, clean=True), gs.predict_kfold(folds, clean=True), np.float64)
+
+
 def test_dense_similarity_equals_sparse_path_on_the_same_input():
     rng = np.random.default_rng(77)
     ns, nq, nt = 500, 100, 64

@@ -24,14 +24,18 @@ def measured_fill(S, alpha):
 def main():
     n = int(os.environ.get("N", 50_000)); nt = int(os.environ.get("NT", 10_000)); folds = int(os.environ.get("FOLDS", 4096))
     alphas = [float(a) for a in os.environ.get("ALPHAS", "0.1,0.5,0.9").split(",")]
+    f64 = os.environ.get("DTYPE", "f32") == "f64"      # the fp64 matrix instruction instead of the bf16 planes
     ss.init(0); ss.use_torch_stream()
     gen = torch.Generator(device="cuda"); gen.manual_seed(20250222 + 4)
     S = sym_uniform(n, gen)
+    if f64:
+        S = S.double()
     yp, yi = rand_csr(n, nt, 0.01, gen)
-    out = torch.empty((folds, nt), dtype=torch.float32, device="cuda")
+    out = torch.empty((folds, nt), dtype=torch.float64 if f64 else torch.float32, device="cuda")
     for alpha in alphas:
         for weighted in (True, False):
-            g = ss.DeviceGraph.from_similarity(None, S, (yp, yi, None, nt), alpha=alpha, weighted=weighted)
+            g = ss.DeviceGraph.from_similarity(None, S, (yp, yi, None, nt), alpha=alpha, weighted=weighted,
+                                               dtype=np.float64 if f64 else np.float32)
             res = None
             for it in range(2):
                 g.predict_loo(0, folds, clean=True, out=out)
