@@ -213,6 +213,16 @@ def c3_loo_curve(args, ss, torch, dist, world, rank, backend):
                                         "bytes_received_per_rank_step": folds * (world - 1) * n * 4,
                                         "how": "direct point-to-point exchange of exact row blocks (grouped ncclSend/ncclRecv)"}
         res["with_gather_to_rank0"] = {"folds_per_s": folds * world * steps / el2, "ms_per_step": el2 / steps * 1e3}
+    if world > 1 and backend == "nccl" and os.environ.get("BENCH_LIB_GATHER") == "1":
+        # opt-in: the same exchange through the library's own RCCL communicator (ss_comm_init / ss_gather_rows_f32) instead
+        # of torch.distributed -- what a Julia caller would use.  Off by default: its peer-to-peer legs cannot be exercised
+        # on the one-GPU boxes this repository is developed on.
+        ids = [ss.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ss.comm_init(ids[0], rank, world)
+        el4, _ = run(lambda: ss.lib_gather_scores(out, counts))
+        ss.comm_destroy()
+        res["with_gather_all_ranks_in_library_rccl"] = {"folds_per_s": folds * world * steps / el4, "ms_per_step": el4 / steps * 1e3}
     el3, _ = run(ex_topl if world > 1 else (lambda: ss.topl(out, 100)))
     res["with_topL_reduction_L100"] = {"folds_per_s": folds * world * steps / el3, "ms_per_step": el3 / steps * 1e3,
                                        "bytes_received_per_rank_step": folds * (world - 1) * 100 * 8,

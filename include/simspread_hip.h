@@ -14,7 +14,8 @@
  *   - every function returns SS_OK (0) or a negative SS_E* code and never throws or
  *     aborts; ss_last_error() returns a thread-local message for the last failure;
  *   - one process drives one GPU (ss_init(device)); multi-GPU = one process per GPU,
- *     rows/folds sharded by the host layer, RCCL only for the final score gather;
+ *     rows/folds sharded by the host layer, RCCL only for the final score gather
+ *     (ss_comm_init / ss_gather_rows_*);
  *   - thread safety: state is handle-scoped.  Calls on DIFFERENT handles may come from several host threads /
  *     Julia tasks at once and overlap; calls on the same handle queue up on that handle's lock; ss_init /
  *     ss_shutdown / ss_set_stream / ss_reset_stream exclude everything else while they run.  ss_last_error,
@@ -90,6 +91,24 @@ int ss_path_last(char* buf, int n);
  * counts since the hold began) instead of replacing one another, so that a benchmark loop need not stop after
  * every call to read them; enable == 0: back to per-call timings. */
 int ss_timing_hold(int enable);
+
+/* ------------------------------------------------------------ final score gather ---- */
+/* The one exchange of the multi-GPU path (north star: "RCCL over xGMI only for the final score gather"; the reference has
+ * no counterpart -- no NCCL/MPI anywhere).  One process per GPU.  Rank 0 fills `id` (128 bytes) with ss_comm_unique_id,
+ * the host framework hands those bytes to the other processes (MPI, Distributed.jl, torch.distributed: any channel), every
+ * process calls ss_comm_init(id, rank, nranks) after ss_init(device).  RCCL is dlopen'ed at that point; a process that
+ * never calls these functions never touches it.
+ * ss_gather_rows_*: rank r holds counts[r] finished rows of the score matrix (`local`, counts[r] x ncols, row-major,
+ * DEVICE memory); the ranks exchange them directly -- one receive per peer straight into its slice of `full`
+ * (sum(counts) x ncols, row-major, DEVICE memory), one send per peer, one ncclGroup on the library stream -- so all
+ * point-to-point xGMI links carry traffic at once.  root < 0: every rank receives the full matrix; root = r: only rank r
+ * does (`full` may be NULL elsewhere).  Stream-ordered like a kernel launch: ss_synchronize() waits for it. */
+int ss_comm_unique_id(char id[128]);
+int ss_comm_init(const char id[128], int rank, int nranks);
+int ss_comm_destroy(void);
+int ss_comm_info(int* rank, int* nranks); /* nranks = 0 when no communicator exists */
+int ss_gather_rows_f32(const float* local, int64_t ncols, const int64_t* counts, float* full, int root);
+int ss_gather_rows_f64(const double* local, int64_t ncols, const int64_t* counts, double* full, int root);
 
 /* ------------------------------------------------------ similarity producer -- */
 /* The step before featurize in the reference's tutorial (docs/src/tutorial/fishers-flowers.jl:66,

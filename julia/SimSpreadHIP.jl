@@ -61,6 +61,37 @@ function path_last()
     return split(unsafe_string(pointer(buf)), ","; keepempty=false)
 end
 
+# ------------------------------------------------------------------------------------------------ final score gather (RCCL)
+"128 bytes created by rank 0; hand them to the other processes (MPI.bcast, Distributed.jl, ...)."
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:ss_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    return id
+end
+comm_init(id::Vector{UInt8}, rank::Integer, nranks::Integer) =
+    check(ccall((:ss_comm_init, LIB), Cint, (Ptr{UInt8}, Cint, Cint), id, rank, nranks))
+comm_destroy() = check(ccall((:ss_comm_destroy, LIB), Cint, ()))
+function comm_info()
+    rank, nranks = Ref{Cint}(0), Ref{Cint}(0)
+    check(ccall((:ss_comm_info, LIB), Cint, (Ref{Cint}, Ref{Cint}), rank, nranks))
+    return Int(rank[]), Int(nranks[])
+end
+
+"""
+    gather_rows(local::Ptr, ncols, counts, full::Ptr; root=-1, T=Float32)
+
+Direct exchange of finished score rows between the ranks (device pointers, row-major blocks): rank r contributes
+`counts[r+1]` rows; `root = -1`: every rank receives the full matrix.
+"""
+function gather_rows(local_::Ptr{Cvoid}, ncols::Integer, counts::Vector{Int64}, full::Ptr{Cvoid}; root::Integer=-1, T::Type=Float32)
+    rc = if T === Float32
+        ccall((:ss_gather_rows_f32, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Cvoid}, Cint), local_, ncols, counts, full, root)
+    else
+        ccall((:ss_gather_rows_f64, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Cvoid}, Cint), local_, ncols, counts, full, root)
+    end
+    check(rc)
+end
+
 # ------------------------------------------------------------------------------------------------ cutoff / k / spread
 "cutoff(X, alpha, weighted) on the device (src/core.jl:37-43,55-60): x >= alpha ? (weighted ? x : 1) : 0."
 function cutoff(X::Matrix{Float64}, alpha::Float64, weighted::Bool=false)

@@ -49,6 +49,12 @@ def _sigs():
         "ss_timing_last": ([_vp, _int], _int),
         "ss_timing_hold": ([_int], _int),
         "ss_path_last": ([_vp, _int], _int),
+        "ss_comm_unique_id": ([_vp], _int),
+        "ss_comm_init": ([_vp, _int, _int], _int),
+        "ss_comm_destroy": ([], _int),
+        "ss_comm_info": ([_vp, _vp], _int),
+        "ss_gather_rows_f32": ([_vp, _i64, _vp, _vp, _int], _int),
+        "ss_gather_rows_f64": ([_vp, _i64, _vp, _vp, _int], _int),
         "ss_graph_destroy": ([_vp], _int),
         "ss_graph_info": ([_vp, _vp], _int),
         "ss_graph_degrees": ([_vp, _vp, _vp, _vp], _int),

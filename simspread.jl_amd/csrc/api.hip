@@ -1059,6 +1059,28 @@ int ss_synchronize(void) {
   return SS_OK;
 }
 
+int ss_comm_unique_id(char id[128]) {
+  SS_API_LOCK();
+  return comm_unique_id(id);
+}
+int ss_comm_init(const char id[128], int rank, int nranks) {
+  SS_API_LOCK();
+  return comm_init(id, rank, nranks);
+}
+int ss_comm_destroy(void) {
+  SS_API_LOCK();
+  return comm_destroy();
+}
+int ss_comm_info(int* rank, int* nranks) { return comm_info(rank, nranks); }
+int ss_gather_rows_f32(const float* local, int64_t ncols, const int64_t* counts, float* full, int root) {
+  SS_API_LOCK();
+  return gather_rows(local, ncols, counts, full, root, 4);
+}
+int ss_gather_rows_f64(const double* local, int64_t ncols, const int64_t* counts, double* full, int root) {
+  SS_API_LOCK();
+  return gather_rows(local, ncols, counts, full, root, 8);
+}
+
 int ss_path_last(char* buf, int n) {
   if (!buf || n <= 0) return fail(SS_EINVAL, "ss_path_last: no buffer");
   const std::string& s = path_note();

@@ -241,4 +241,11 @@ int launch_unpermute(const T* in, int64_t ldin, int64_t nrows, int64_t nt, const
 template <class T>
 int launch_loo_clean_fix(const DevCsr<T>& YsT, const int* kt, int64_t i_begin, int64_t nrows, T* out, int64_t ld);
 
+// ---- comm.hip: in-library score gather over RCCL (dlopen'ed), one process per GPU
+int comm_unique_id(char* id128);
+int comm_init(const char* id128, int rank, int nranks);
+int comm_destroy();
+int comm_info(int* rank, int* nranks);
+int gather_rows(const void* local, int64_t ncols, const int64_t* counts, void* full, int root, int elem);
+
 }  // namespace ss

@@ -95,3 +95,49 @@ def gather_topl(idx, val, n_total: int, group=None, root: Optional[int] = None, 
     BASELINE configs[2] 80 MB instead of 40 GB for L = 100.  Same direct exchange as gather_scores."""
     return (gather_scores(idx, n_total, group=group, root=root, counts=counts),
             gather_scores(val, n_total, group=group, root=root, counts=counts))
+
+
+# ---------------------------------------------------------------------------------------------- in-library gather
+def comm_unique_id() -> bytes:
+    """128 bytes created by rank 0 (ss_comm_unique_id); hand them to the other ranks over any channel."""
+    import ctypes as C
+    from . import _lib as L
+    buf = C.create_string_buffer(128)
+    L.check(L.lib().ss_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return buf.raw
+
+
+def comm_init(unique_id: bytes, rank: int, nranks: int) -> None:
+    """Create this process's RCCL communicator inside the library (after ss.init(device))."""
+    import ctypes as C
+    from . import _lib as L
+    if len(unique_id) != 128:
+        raise ValueError("the unique id is 128 bytes")
+    buf = C.create_string_buffer(unique_id, 128)
+    L.check(L.lib().ss_comm_init(C.cast(buf, C.c_void_p), int(rank), int(nranks)))
+
+
+def comm_destroy() -> None:
+    from . import _lib as L
+    L.check(L.lib().ss_comm_destroy())
+
+
+def lib_gather_scores(local, counts: Sequence[int], root: Optional[int] = None):
+    """gather_scores through the library's own RCCL communicator (ss_gather_rows_*): torch CUDA tensors in, the full
+    matrix (or None on non-receiving ranks) out.  Same direct exchange, no torch.distributed involved."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    if not (local.is_cuda and local.is_contiguous()):
+        raise TypeError("local must be a contiguous CUDA tensor")
+    rank, nranks = C.c_int(), C.c_int()
+    L.check(L.lib().ss_comm_info(C.byref(rank), C.byref(nranks)))
+    if nranks.value > 0 and (nranks.value != len(counts) or counts[rank.value] != local.shape[0]):
+        raise ValueError("counts do not match the communicator / the local block")
+    receives = root is None or root == rank.value
+    full = torch.empty((int(sum(counts)), local.shape[1]), dtype=local.dtype, device=local.device) if receives else None
+    cnt = (C.c_int64 * len(counts))(*[int(c) for c in counts])
+    fn = L.lib().ss_gather_rows_f32 if local.dtype == torch.float32 else L.lib().ss_gather_rows_f64
+    L.check(fn(local.data_ptr(), local.shape[1], cnt, None if full is None else full.data_ptr(), -1 if root is None else int(root)))
+    L.check(L.lib().ss_synchronize())
+    return full

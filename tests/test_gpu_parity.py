@@ -253,6 +253,30 @@ def test_two_threads_two_handles():
     assert not errors, errors[:3]
 
 
+def test_in_library_rccl_gather_single_rank():
+    """ss_comm_* / ss_gather_rows_*: the library's own RCCL communicator (dlopen'ed).  A one-GPU box allows exactly one
+    rank per device, so this covers loading RCCL, creating / destroying the communicator, the own-block path of the
+    exchange and the argument checks; the peer-to-peer legs run in the driver's multi-GPU job only."""
+    import torch
+    ss.use_torch_stream()
+    with pytest.raises(ss.SimSpreadError):
+        ss.lib_gather_scores(torch.zeros((2, 3), device="cuda"), [2])          # no communicator yet
+    uid = ss.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ss.comm_init(uid, 0, 1)
+    for dt in (torch.float32, torch.float64):
+        local = torch.arange(5 * 7, device="cuda", dtype=dt).reshape(5, 7).contiguous()
+        assert torch.equal(ss.lib_gather_scores(local, [5]), local)             # every rank receives
+        assert torch.equal(ss.lib_gather_scores(local, [5], root=0), local)     # gather to rank 0
+    with pytest.raises(ValueError):
+        ss.lib_gather_scores(local, [4])
+    ss.comm_destroy()
+    with pytest.raises(ss.SimSpreadError):
+        ss.lib_gather_scores(local, [5])
+    with pytest.raises(ss.SimSpreadError):
+        ss.comm_init(uid, 3, 2)                                                  # rank outside the communicator
+
+
 def test_multi_chunk_and_row_batches(monkeypatch):
     # force several LDS chunks of W's columns and several transfer batches; results must not change
     Xq, Xs, Ys = O.synth_bipartite(150, 700, 700, 300, 0.05, 0.03, seed=9, dtype=np.float32)
