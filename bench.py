@@ -315,6 +315,8 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the configs[2] leave-one-out curve")
     ap.add_argument("--dense-n", type=int, default=3000, help="literal dense CPU baseline: nodes per layer (N = 4x this)")
+    ap.add_argument("--aux-timeout", type=int, default=300,
+                    help="N > 1: seconds the auxiliary legs (configs[2] curve) may take before the headline line is printed without them")
     ap.add_argument("--gather", action="store_true", help="also time the final gather of the C2 score blocks (outside `value`)")
     args = ap.parse_args()
 
@@ -388,12 +390,21 @@ def main():
         barrier()
         gather_ms = (time.perf_counter() - tg) * 1e3
 
-    c3 = None
-    if not args.no_c3:
-        try:
-            c3 = c3_loo_curve(args, ss, torch, dist, world, rank, backend)
-        except Exception as e:  # auxiliary: never lose the headline line
-            c3 = {"error": repr(e)}
+    result = None
+    state = {"printed": False}
+
+    def emit(extra=None):
+        # the ONE JSON line of the contract (rank 0), whatever happens to the auxiliary legs
+        if rank == 0 and result is not None and not state["printed"]:
+            state["printed"] = True
+            if extra:
+                result.update(extra)
+            print(json.dumps(result), flush=True)
+
+    def watchdog():
+        # an auxiliary leg did not come back (a peer died inside an exchange, a hung collective): keep the headline
+        emit({"c3_loo": {"error": "auxiliary leg exceeded %d s; dropped" % args.aux_timeout}})
+        os._exit(0)
 
     if rank == 0:
         nnz_w = g.nnz_ys
@@ -456,8 +467,23 @@ def main():
         }
         if gather_ms is not None:
             result["score_gather_ms"] = gather_ms
-        if c3 is not None:
+
+    # ---- auxiliary legs, after the headline numbers are final and under a watchdog (never lose the headline line)
+    timer = None
+    if world > 1:
+        import threading
+        timer = threading.Timer(args.aux_timeout, watchdog)
+        timer.daemon = True
+        timer.start()
+    if not args.no_c3:
+        try:
+            c3 = c3_loo_curve(args, ss, torch, dist, world, rank, backend)
+        except Exception as e:
+            c3 = {"error": repr(e)}
+        if rank == 0:
             result["c3_loo"] = c3
+
+    if rank == 0:
         if not args.no_sweep and world == 1:
             try:
                 result["spmm_narrow_sweep"] = spmm_sweep(ss, torch)
@@ -498,9 +524,14 @@ def main():
                 result["cpu_baseline"]["literal_dense"] = literal_dense_baseline(ss, args.dense_n, args.dx, args.dy)
             except Exception as e:
                 result["cpu_baseline"]["literal_dense"] = {"error": repr(e)}
-        print(json.dumps(result))
+    emit()
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    if timer is not None:
+        timer.cancel()
 
 
 if __name__ == "__main__":
