@@ -748,7 +748,7 @@ constexpr int NARROW_THREADS = 1024;
 
 // GL = lanes that share one sub-row (64, 32, 16 or 8: the power of two above the mean sub-row length in
 // quads), so a wave streams 64/GL rows at once; UR row groups are unrolled to keep more loads in flight.
-template <class T, int VEC, int LPN, int GL, int UR>
+template <class T, int VEC, int LPN, int GL, int UR, int NBQ>
 __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(NarrowArgs<T> a) {
   constexpr int BV = VEC * LPN;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -794,55 +794,97 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
     const ushort4* __restrict__ ip = reinterpret_cast<const ushort4*>(a.idx);
     const Vec<T, 4>* __restrict__ vp = reinterpret_cast<const Vec<T, 4>*>(a.val);
     const int64_t stride = (int64_t)nslots * nwaves * RPS * UR;
-    for (int64_t mb = ((int64_t)slot * nwaves + wave) * RPS * UR; mb < a.M; mb += stride) {
-      int o[UR], oe[UR];
-      ushort4 iv[UR];
-      Vec<T, 4> w[UR];
-      T acc[UR][VEC];
+    // Software pipeline over the row groups of this wave: while group i is gathered, the quads of group i+1 are in
+    // flight and the sub-row bounds of group i+2 are being read, so the W stream never waits for a dependent load.
+    // Every lane requests NBQ quads per row unconditionally (q, q + GL, ...; clamped to a valid quad, masked below):
+    // loads stay out of branches and their waits stay counted.  Rows longer than NBQ * GL quads take the rolled tail.
+    struct Bounds { int lo[UR], hi[UR]; };   // raw off[m], off[m + 1] (row clamped; validity is applied at use)
+    // quads in flight for one row group; mask bit u*NBQ + nb: this lane's quad nb of row u is inside the sub-row,
+    // bit 31: some row of the group is longer than NBQ * GL quads
+    struct Quads { ushort4 iv[UR][NBQ]; Vec<T, 4> w[UR][NBQ]; unsigned mask; };
+    auto bounds = [&](int64_t mb, Bounds& b) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < UR; ++u) {
         const int64_t m = mb + u * RPS + sub;
-        o[u] = m < a.M ? off[m] : 0;
-        oe[u] = m < a.M ? off[m + 1] : 0;
+        const int64_t mm = m < a.M ? m : a.M - 1;
+        b.lo[u] = off[mm];
+        b.hi[u] = off[mm + 1];
       }
+    };
+    auto issue = [&](int64_t mb, const Bounds& b, Quads& x) __attribute__((always_inline)) {
+      unsigned mask = 0;
 #pragma unroll
       for (int u = 0; u < UR; ++u) {
-        const int q = o[u] + gl;
-        const int qq = q < oe[u] ? q : o[u];  // a valid address; masked below
-        iv[u] = ip[qq];
-        w[u] = vp[qq];
+        const int oe = (mb + u * RPS + sub < a.M) ? b.hi[u] : b.lo[u];
+#pragma unroll
+        for (int nb = 0; nb < NBQ; ++nb) {
+          const int q = b.lo[u] + gl + nb * GL;
+          const bool in = q < oe;
+          const int qq = in ? q : b.lo[u];
+          x.iv[u][nb] = ip[qq];
+          x.w[u][nb] = vp[qq];
+          mask |= in ? (1u << (u * NBQ + nb)) : 0u;
+        }
+        mask |= (b.lo[u] + NBQ * GL < oe) ? 0x80000000u : 0u;
       }
+      x.mask = mask;
+    };
+    auto quad = [&](T (&acc)[VEC], const ushort4 jv, const Vec<T, 4> x) __attribute__((always_inline)) {
+      const V r0 = tile_row((int)jv.x);
+      const V r1 = tile_row((int)jv.y);
+      const V r2 = tile_row((int)jv.z);
+      const V r3 = tile_row((int)jv.w);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        acc[i] = fma(x.v[0], r0.v[i], acc[i]);
+        acc[i] = fma(x.v[1], r1.v[i], acc[i]);
+        acc[i] = fma(x.v[2], r2.v[i], acc[i]);
+        acc[i] = fma(x.v[3], r3.v[i], acc[i]);
+      }
+    };
+    int64_t mb = ((int64_t)slot * nwaves + wave) * RPS * UR;
+    Bounds bn;
+    Quads xa, xb;
+    if (mb < a.M) {
+      Bounds b0;
+      bounds(mb, b0);
+      bounds(mb + stride < a.M ? mb + stride : mb, bn);
+      issue(mb, b0, xa);
+    }
+    // one row group: request the quads of the next group (its bounds arrived a step ago) and the bounds of the one
+    // after, then gather the current group.  Two copies of the step alternate the quad registers (a copy of a
+    // register with a load in flight would wait for it); only the bounds, long arrived, are moved.
+    auto step = [&](const int64_t mb, const Quads& xc, Quads& xn) __attribute__((always_inline)) {
+      // unconditional (the last group re-requests itself): no load sits in a branch
+      const int64_t mb1 = mb + stride < a.M ? mb + stride : mb;
+      const int64_t mb2 = mb + 2 * stride < a.M ? mb + 2 * stride : mb;
+      Bounds bnn;
+      bounds(mb2, bnn);
+      issue(mb1, bn, xn);
+      __builtin_amdgcn_sched_barrier(0);  // the requests go out BEFORE the gathers of the current group (hipcc sinks them otherwise)
+      T acc[UR][VEC];
 #pragma unroll
       for (int u = 0; u < UR; ++u) {
-        const bool has = o[u] + gl < oe[u];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[u][i] = T(0);
-        if (has) {
-          const V r0 = tile_row((int)iv[u].x);
-          const V r1 = tile_row((int)iv[u].y);
-          const V r2 = tile_row((int)iv[u].z);
-          const V r3 = tile_row((int)iv[u].w);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            acc[u][i] = fma(w[u].v[0], r0.v[i], acc[u][i]);
-            acc[u][i] = fma(w[u].v[1], r1.v[i], acc[u][i]);
-            acc[u][i] = fma(w[u].v[2], r2.v[i], acc[u][i]);
-            acc[u][i] = fma(w[u].v[3], r3.v[i], acc[u][i]);
-          }
+        for (int nb = 0; nb < NBQ; ++nb) {
+          // lanes past the end of the sub-row hold a clamped (valid) quad: gather it with zero weights
+          const bool has = (xc.mask >> (u * NBQ + nb)) & 1u;
+          Vec<T, 4> w = xc.w[u][nb];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w.v[e] = has ? w.v[e] : T(0);
+          quad(acc[u], xc.iv[u][nb], w);
         }
-        for (int q = o[u] + gl + GL; q < oe[u]; q += GL) {  // sub-rows longer than one group step
-          const ushort4 jv = ip[q];
-          const Vec<T, 4> x = vp[q];
-          const V r0 = tile_row((int)jv.x);
-          const V r1 = tile_row((int)jv.y);
-          const V r2 = tile_row((int)jv.z);
-          const V r3 = tile_row((int)jv.w);
+      }
+      if (__any((int)(xc.mask >> 31))) {
+        // rows longer than the NBQ * GL quads requested ahead (rare by the choice of GL): bounds re-read, rolled loop
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            acc[u][i] = fma(x.v[0], r0.v[i], acc[u][i]);
-            acc[u][i] = fma(x.v[1], r1.v[i], acc[u][i]);
-            acc[u][i] = fma(x.v[2], r2.v[i], acc[u][i]);
-            acc[u][i] = fma(x.v[3], r3.v[i], acc[u][i]);
+        for (int u = 0; u < UR; ++u) {
+          const int64_t m = mb + u * RPS + sub;
+          if (m < a.M) {
+            const int lo = off[m], hi = off[m + 1];
+            for (int q = lo + gl + NBQ * GL; q < hi; q += GL) quad(acc[u], ip[q], vp[q]);
           }
         }
       }
@@ -865,6 +907,14 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
           }
         }
       }
+      bn = bnn;
+    };
+    while (mb < a.M) {
+      step(mb, xa, xb);
+      mb += stride;
+      if (mb >= a.M) break;
+      step(mb, xb, xa);
+      mb += stride;
     }
   } else {
     // LPN lanes share a non-zero (each fetches VEC of the BV columns); a group of GL lanes shares a row
@@ -953,27 +1003,43 @@ int narrow_chunk_cols(int bv) {
   return (int)kc;
 }
 
-template <class T, int VEC, int LPN, int GL, int UR>
+template <class T, int VEC, int LPN, int GL, int UR, int NBQ = 1>
 static int launch_narrow_variant(const NarrowArgs<T>& a, unsigned grid, size_t lds) {
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR>),
+    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR, NBQ>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR>), dim3(grid), dim3(NARROW_THREADS), lds,
+  hipLaunchKernelGGL((spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR, NBQ>), dim3(grid), dim3(NARROW_THREADS), lds,
                      ctx().stream, a);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
 
+// Row groups per step (UR) such that two sets of quads in flight (UR * NBQ quads of 8 + 4*sizeof(T) bytes per lane and
+// set), the UR * VEC accumulators, four gathered tile rows and the bounds stay inside the 128 registers a lane has at 16
+// waves per CU.
+constexpr int narrow_ur(int elem, int vec, int nbq) {
+  const int per_quad = 2 + elem;  // registers
+  int ur = 4;
+  while (ur > 1 && 2 * ur * nbq * per_quad + (ur + 4) * vec * (elem / 4) + 4 * ur + 24 > 124) ur >>= 1;
+  return ur;
+}
+
 template <class T, int VEC>
 static int launch_narrow_lpn1(const NarrowArgs<T>& a, unsigned grid, size_t lds, double mean_quads) {
-  constexpr int UR = VEC >= 8 ? 2 : 4;  // accumulators per lane = UR * VEC; stay inside 128 VGPRs
-  if (mean_quads > 40.0) return launch_narrow_variant<T, VEC, 1, 64, (VEC <= 2 ? 4 : 2)>(a, grid, lds);
-  if (mean_quads > 20.0) return launch_narrow_variant<T, VEC, 1, 32, UR>(a, grid, lds);
-  if (mean_quads > 10.0) return launch_narrow_variant<T, VEC, 1, 16, UR>(a, grid, lds);
-  return launch_narrow_variant<T, VEC, 1, 8, UR>(a, grid, lds);
+  constexpr int E = (int)sizeof(T);
+  // GL lanes per row, one request per lane (two above 64 quads): the smallest capacity about 10 % above the mean
+  // sub-row length in quads.  Measured (100k x 100k, 1 %): lanes past the end of a sub-row are not free (a step is
+  // bound by the latency of its requests, so rows per step count: B = 4, mean 25 quads, 32 vs 64 lanes per row
+  // 0.20 vs 0.35 ms), while the rolled tail for the few longer rows costs little
+  const double need = 1.1 * mean_quads + 1.0;
+  if (need > 64.0) return launch_narrow_variant<T, VEC, 1, 64, narrow_ur(E, VEC, 2), 2>(a, grid, lds);
+  if (need > 32.0) return launch_narrow_variant<T, VEC, 1, 64, narrow_ur(E, VEC, 1)>(a, grid, lds);
+  if (need > 16.0) return launch_narrow_variant<T, VEC, 1, 32, narrow_ur(E, VEC, 1)>(a, grid, lds);
+  if (need > 8.0) return launch_narrow_variant<T, VEC, 1, 16, narrow_ur(E, VEC, 1)>(a, grid, lds);
+  return launch_narrow_variant<T, VEC, 1, 8, narrow_ur(E, VEC, 1)>(a, grid, lds);
 }
 
 // B = 8 / 16: group size so that a mean sub-row takes about two group steps

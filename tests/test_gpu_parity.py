@@ -488,6 +488,29 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
         assert_close(ws.spmm(R.astype(dt)), W @ R, dt)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("mean_entries", [6, 40, 100, 210, 380])
+def test_spmm_narrow_every_group_size(mean_entries, dtype):
+    """The HBM-bound narrow kernel picks 8 / 16 / 32 / 64 lanes per row (and two requests per lane) from the mean sub-row
+    length; every variant runs its software pipeline (quads of the next row group in flight, bounds of the one after)
+    over a row count that is no multiple of a step, with empty rows and a few rows far longer than the requests
+    cover (rolled tail)."""
+    rng = np.random.default_rng(mean_entries)
+    M, K = 1237, 6000
+    lens = rng.poisson(mean_entries, M)
+    lens[::13] = 0
+    lens[5] = min(K, 6 * mean_entries + 300)
+    lens[M - 1] = min(K, 5 * mean_entries + 100)
+    rows = [np.sort(rng.choice(K, int(n), replace=False)) for n in lens]
+    indptr = np.cumsum([0] + [len(r) for r in rows])
+    W = sp.csr_matrix((rng.random(indptr[-1]) + 0.1, np.concatenate(rows), indptr), shape=(M, K))
+    R = rng.standard_normal((K, 4))
+    w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
+    for B in (1, 2, 3, 4):
+        assert_close_signed(w.spmm(R[:, :B].astype(dtype)), W @ R[:, :B], dtype)
+        assert "spmm_chunked_narrow" in ss.path_last()
+
+
 @pytest.mark.parametrize("binary", [False, True])
 @pytest.mark.parametrize("dtype,B", [(np.float32, 12), (np.float32, 16), (np.float32, 28), (np.float32, 64), (np.float32, 52),
                                      (np.float64, 6), (np.float64, 16), (np.float64, 32)])
