@@ -37,7 +37,10 @@ for k in fetch:
                          "l2_hit_rate": (l2hit.get(k, 0) / l2req[k]) if l2req.get(k) else None,
                          "lds_busy_frac": ((ldsact.get(k, 0) / 256) / (grbm[k] / 8)) if grbm.get(k) else None,
                          "avg_duration_us": (sum(dur[k]) / len(dur[k]) / 1e3) if k in dur else None}
-for name in (f"pmc_{tag}.json", "pmc_latest.json"):
-    with open(os.path.join(root, "profiles", name), "w") as f:
-        json.dump(out, f, indent=1)
+# profiles/ is what gets committed; on a GPU box only gpurun_out/ travels back, so a copy goes there too
+for d in ("profiles", "gpurun_out"):
+    if os.path.isdir(os.path.join(root, d)):
+        for name in (f"pmc_{tag}.json", "pmc_latest.json"):
+            with open(os.path.join(root, d, name), "w") as f:
+                json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))
