@@ -83,7 +83,7 @@ int ss_synchronize(void);
 int ss_timing_last(double* ms, int n);
 /* Which kernels the last predict / spmm call of this host thread went through: a comma-separated list of tags
  * ("transfer", "transfer_loo", "transfer_dense_bf16_ring", "transfer_dense_bf16_128", "transfer_dense_f32_mfma",
- * "spmm_sell", "spmm_sell_sorted", "spmm_colgroup", "spmm_rowblock", "spmm_chunked_narrow", ...), NUL-terminated, truncated
+ * "spmm_sell", "spmm_sell_sorted", "spmm_colgroup", "spmm_chunked_narrow", ...), NUL-terminated, truncated
  * to n - 1 characters.  Lets a caller (and the parity tests) assert that a size-dependent routing decision was the one
  * expected.  Has no counterpart in the reference (its only switch is GPU::Bool, src/core.jl:402,404). */
 int ss_path_last(char* buf, int n);

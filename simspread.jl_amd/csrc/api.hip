@@ -766,43 +766,27 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   }
   hipEvent_t e_begin, e_end;
   SS_TRY(timing_mark(&e_begin));
-  // row-major operands: B <= 7 streams W once with R chunks in LDS (HBM-bound kernel); 32 < B <= 64 goes, by
-  // default, to the wide LDS-tiled kernel with the slices split over workgroups (W is then streamed B/4 times:
-  // measured at 100k x 100k / 1 %: B=64 1.18 ms vs 4.9 ms for the register-accumulator kernel
-  // (SS_NARROW_REGACC=1) and 5.6 ms for gathering rows of R from L2 (SS_NARROW_CSR=1))
-  int wide_from = 9;
-  if (const char* e = getenv("SS_WIDE_FROM")) wide_from = atoi(e);
-  // 8 <= B <= 32 (fp64: 8 < B <= 16), row-major: row-block kernel (spmm_mid.hip): W streamed once, no partial
-  // sums.  Measured at 100k x 100k / 1 %: B=8 0.23 ms (narrow kernel 0.33), B=16 0.37 ms (wide kernel 0.56),
-  // B=32 0.74 (1.03); SS_MID=0: the other kernels
-  // fp32: 32-byte tile rows serve B = 8 (0.23 ms vs 0.33 ms narrow); B = 5..7 cannot be staged in 16-byte pieces
-  // and are no faster than the narrow kernel
-  int mid_from = sizeof(T) == 4 ? 8 : 9;
-  if (const char* e = getenv("SS_MID_FROM")) mid_from = atoi(e);
-  const bool mid = (B >= mid_from && B * (int64_t)sizeof(T) <= 128 && r_layout == SS_LAYOUT_ROWMAJOR &&
-                    f_layout == SS_LAYOUT_ROWMAJOR && !(getenv("SS_MID") && atoi(getenv("SS_MID")) == 0) &&
-                    getenv("SS_WIDE_FROM") == nullptr && getenv("SS_NARROW_REGACC") == nullptr &&
-                    getenv("SS_NARROW_CSR") == nullptr);
-  const bool wide_for_mid = (B >= wide_from && getenv("SS_NARROW_REGACC") == nullptr && getenv("SS_NARROW_CSR") == nullptr);
-  const bool narrow = (B <= 64 && r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR && !wide_for_mid);
-  DevBuf<T> Rt, Ft;
-  const bool use_csr_gather = getenv("SS_NARROW_CSR") != nullptr;
-  // 2-D cut with conflict-free gathers (spmm_colgroup.hip): tile rows of 64 .. 256 bytes, i.e. fp32 16 <= B <= 64 (by
-  // default from B = 9, where the 64-byte tile row starts to pay), fp64 up to B = 32.  SS_COL=0: the kernels below
-  int col_from = sizeof(T) == 4 ? 9 : 5;
+  // Routing by width, row-major operands (measured at 100k x 100k / 1 %):
+  //   B <= 4                          narrow kernel: W streamed once, the chunk of R in LDS, lanes of a row folded -- the
+  //                                   HBM-bound regime (B = 1 0.13 ms = 4.6 TB/s of the 6 B/nnz operand)
+  //   5 <= B, B*sizeof(T) <= 256 B    2-D kernel (spmm_colgroup.hip): tile rows of 64 / 128 / 256 bytes (fp32 B <= 64, fp64 <= 32);
+  //                                   B = 5..16 0.22-0.24 ms, 32 0.44, 64 0.9
+  //   wider, and pattern-only W (every value 1) above 128-byte tile rows: the SELL kernel of stage 2, which re-streams only
+  //                                   the 2-byte indices (B = 64: 0.61 vs 0.82 ms); column-major operands always
+  // SS_COL=0: no 2-D kernel (SELL instead); SS_COL_FROM: its first B, pattern-only wide cases included (comparisons, tests)
+  const bool rowmajor = r_layout == SS_LAYOUT_ROWMAJOR && f_layout == SS_LAYOUT_ROWMAJOR;
+  int col_from = 5;
   if (const char* e = getenv("SS_COL_FROM")) col_from = atoi(e);
-  // pattern-only W (every value 1) wider than a 128-byte tile row: the wide SELL kernel re-streams only the 2-byte indices
-  // and is faster there (B = 64: 0.61 ms vs 0.82 ms); with values the 2-D kernel wins (0.93 ms vs 1.27 ms)
   const bool col_wide_ok = !(m.csr.binary && B * (int64_t)sizeof(T) > 128) || getenv("SS_COL_FROM") != nullptr;
-  const bool col = (B >= col_from && B * (int64_t)sizeof(T) <= 256 && col_wide_ok && r_layout == SS_LAYOUT_ROWMAJOR &&
-                    f_layout == SS_LAYOUT_ROWMAJOR && !(getenv("SS_COL") && atoi(getenv("SS_COL")) == 0) &&
-                    getenv("SS_WIDE_FROM") == nullptr && getenv("SS_NARROW_REGACC") == nullptr &&
-                    getenv("SS_NARROW_CSR") == nullptr && getenv("SS_MID_FROM") == nullptr);
+  const bool col = rowmajor && B >= col_from && B * (int64_t)sizeof(T) <= 256 && col_wide_ok &&
+                   !(getenv("SS_COL") && atoi(getenv("SS_COL")) == 0);
+  const bool narrow = rowmajor && B <= 4;
+  DevBuf<T> Rt, Ft;
   if (col) {
     const int rowb = B * (int64_t)sizeof(T) <= 64 ? 64 : (B * (int64_t)sizeof(T) <= 128 ? 128 : 256);
-    const int slot = rowb == 64 ? 0 : (rowb == 128 ? 1 : 3);
+    const int slot = rowb == 64 ? 0 : (rowb == 128 ? 1 : 2);
     const int bv = rowb / (int)sizeof(T);
-    DevChunked<T>& op = m.mid[slot];
+    DevChunked<T>& op = m.col[slot];
     if (op.SC == 0) {
       int kc = colgroup_chunk_cols<T>(bv);
       if (const char* e = getenv("SS_NARROW_CHUNK")) {
@@ -814,25 +798,7 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
     StageTimer t2(ST_SPMM);
     SS_TRY(launch_spmm_colgroup<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
     timing_count(ST_NSPMM, 1);
-  } else if (mid) {
-    // 32-byte tile rows (8 floats), 64-byte (16 floats) or 128-byte (32 floats, 16 doubles)
-    const int rowb = (B * (int64_t)sizeof(T) <= 32 && sizeof(T) == 4) ? 32 : ((B <= 16 && sizeof(T) == 4) ? 64 : 128);
-    const int slot = rowb == 32 ? 2 : (rowb == 64 ? 0 : 1);
-    const int bv = rowb / (int)sizeof(T);
-    DevChunked<T>& op = m.mid[slot];
-    if (op.SC == 0) {
-      int kc = mid_chunk_cols<T>(bv);
-      if (const char* e = getenv("SS_NARROW_CHUNK")) {
-        const int v = atoi(e);
-        if (v >= 16 && v < kc) kc = v;
-      }
-      SS_TRY(chunked_build<T>(m.csr, kc, 4, op));
-    }
-    StageTimer t2(ST_SPMM);
-    SS_TRY(launch_spmm_rowblock<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d));
-    timing_count(ST_NSPMM, 1);
-  } else if (narrow && B <= 16 && !use_csr_gather) {
-    // R chunk resident in LDS, W streamed once in chunk-major order (HBM-bound regime)
+  } else if (narrow) {
     int slot = 0, bv = 1;
     while (bv < B) { bv <<= 1; ++slot; }
     DevChunked<T>& op = m.narrow[slot];
@@ -846,25 +812,6 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
     }
     StageTimer t2(ST_SPMM);
     SS_TRY(launch_spmm_chunked_narrow<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
-    timing_count(ST_NSPMM, 1);
-  } else if (narrow && std::is_same<T, float>::value && !use_csr_gather) {
-    // comparison kernel (SS_NARROW_REGACC=1), 16 < B <= 64: accumulators in registers, R chunks in LDS, W read once
-    if constexpr (std::is_same<T, float>::value) {
-      if (m.pairs.KC == 0) {
-        int kc = 640;  // 640 rows x 64 floats = 160 KB
-        if (const char* e = getenv("SS_NARROW_CHUNK")) {
-          const int v = atoi(e);
-          if (v >= 16 && v < kc) kc = v;
-        }
-        SS_TRY(pairs_build(m.csr, kc, 256, m.pairs));
-      }
-      StageTimer t2(ST_SPMM);
-      SS_TRY(launch_spmm_regacc(m.pairs, Rd, ldr_d, (int)B, Fd, ldf_d));
-      timing_count(ST_NSPMM, 1);
-    }
-  } else if (narrow) {
-    StageTimer t2(ST_SPMM);
-    SS_TRY(launch_spmm_csr_narrow<T>(m.csr, Rd, ldr_d, (int)B, Fd, ldf_d));
     timing_count(ST_NSPMM, 1);
   } else {
     const int qt = sell_tile_width<T>();

@@ -857,53 +857,6 @@ int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out) {
   return SS_OK;
 }
 
-// ------------------------------------------------------------------ CSR -> chunk-major (offset, value) pairs
-__global__ void pairs_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const float* __restrict__ val,
-                                  int64_t rows, int KC, int nchunks, int row_bytes, const int* __restrict__ off,
-                                  uint2* __restrict__ ent) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t total = rows * nchunks;
-  for (int64_t i = wave0; i < total; i += nwaves) {
-    const int c = (int)(i / rows);
-    const int64_t r = i - (int64_t)c * rows;
-    const int o = off[i], n = off[i + 1] - o;
-    if (n == 0) continue;
-    const int lo = ptr[r], hi = ptr[r + 1];
-    const int64_t k0 = (int64_t)c * KC;
-    int a = lo, b = hi;
-    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
-    for (int x = lane; x < n; x += 64)
-      ent[o + x] = make_uint2((unsigned)((idx[a + x] - k0) * row_bytes), __float_as_uint(val[a + x]));
-  }
-}
-
-int pairs_build(const DevCsr<float>& in, int KC, int row_bytes, DevPairs& out) {
-  hipStream_t st = ctx().stream;
-  out.rows = in.rows; out.cols = in.cols; out.nnz = in.nnz; out.KC = KC; out.row_bytes = row_bytes;
-  out.nchunks = (int)(in.cols > 0 ? ceil_div(in.cols, KC) : 1);
-  const int64_t total = in.rows * out.nchunks;
-  SS_TRY(out.off.alloc(total + 1));
-  SS_TRY(out.ent.alloc(in.nnz + 8));
-  SS_HIP(hipMemsetAsync(out.ent.p + in.nnz, 0, 8 * sizeof(uint2), st));
-  if (total == 0) {
-    SS_HIP(hipMemsetAsync(out.off.p, 0, sizeof(int), st));
-    return SS_OK;
-  }
-  DevBuf<int> cnt;
-  SS_TRY(cnt.alloc(total));
-  hipLaunchKernelGGL(chunk_count_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p, in.rows, KC,
-                     out.nchunks, 1, cnt.p);
-  SS_LAUNCH_CHECK();
-  SS_TRY(exclusive_scan_int(cnt.p, out.off.p, total));
-  hipLaunchKernelGGL(pairs_fill_kernel, dim3(grid_for(total * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p, in.val.p,
-                     in.rows, KC, out.nchunks, row_bytes, out.off.p, out.ent.p);
-  SS_LAUNCH_CHECK();
-  SS_HIP(hipStreamSynchronize(st));
-  return SS_OK;
-}
-
 // ------------------------------------------------------------------ degrees + transposes of a graph
 template <class T>
 __global__ void degree_kernel(const int* __restrict__ pa, const int* __restrict__ pb, int64_t n, int* __restrict__ k,

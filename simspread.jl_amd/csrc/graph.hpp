@@ -96,25 +96,14 @@ struct Graph {
   DevBuf<T> Sws;  // workspace: sorted-order scores of a skew-sorted stage-2 operand
 };
 
-// Chunk-major (row offset, value) pairs for the register-accumulator SpMM (16 < B <= 64, fp32): the
-// 32-bit first word is the byte offset of the row of R inside the LDS tile, so an entry is consumed as a
-// scalar pair (s_load) and one ds_read.
-struct DevPairs {
-  int64_t rows = 0, cols = 0, nnz = 0;
-  int KC = 0, nchunks = 0, row_bytes = 0;
-  DevBuf<int> off;        // [nchunks*rows + 1]
-  DevBuf<uint2> ent;      // [nnz + 8]
-};
-
 template <class T>
 struct SpMat {
   DevCsr<T> csr;
   DevSell<T> sell;
   int sell_qt = 0;
-  DevChunked<T> narrow[5];  // quad-aligned chunked operands for B <= 1, 2, 4, 8, 16 (built lazily)
-  DevChunked<T> mid[4];     // operands of the mid-width kernels: 64-, 128-, 32- and 256-byte tile rows (built lazily)
-  DevPairs pairs;           // operand of the register-accumulator kernel (16 < B <= 64, fp32)
-  DevBuf<T> partial;        // [nchunks][rows][BV] partial sums of the narrow kernel
+  DevChunked<T> narrow[3];  // quad-aligned chunked operands of the narrow kernel for B <= 1, 2, 4 (built lazily)
+  DevChunked<T> col[3];     // operands of the 2-D kernel: 64-, 128- and 256-byte tile rows (built lazily)
+  DevBuf<T> partial;        // partial sums of the narrow / 2-D kernels (and the padded copy of R, spmm_colgroup.hip)
 };
 
 // ---- assemble.hip
@@ -186,25 +175,14 @@ int narrow_chunk_cols(int bv);  // KC for a padded width bv
 template <class T>
 int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
                                DevBuf<T>& partial);
-// stage 2, mid width (8 <= B <= 32; fp64: 8 < B <= 16): a workgroup owns rows, accumulators stay in registers while the
-// chunks of R cycle through LDS (spmm_mid.hip); same chunked operand format as the narrow kernel
-template <class T>
-int mid_chunk_cols(int bv);
-template <class T>
-int launch_spmm_rowblock(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
-// stage 2, mid width, 2-D cut (row blocks x chunk groups) with conflict-free gathers (spmm_colgroup.hip): tile rows of
-// 64, 128 or 256 bytes (fp32: B <= 16, 32, 64; fp64: B <= 8, 16, 32); same chunked operand
+// stage 2, mid width (5 <= B, B*sizeof(T) <= 256 bytes): 2-D cut (row blocks x chunk groups) with conflict-free gathers
+// (spmm_colgroup.hip): tile rows of 64, 128 or 256 bytes (fp32: B <= 16, 32, 64; fp64: B <= 8, 16, 32); same chunked
+// operand format as the narrow kernel
 template <class T>
 int colgroup_chunk_cols(int bv);
 template <class T>
 int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr, int B, T* F, int64_t ldf,
                          DevBuf<T>& partial);
-// comparison kernel (SS_NARROW_REGACC=1), 16 < B <= 64 (fp32): accumulators in registers (lane = column), entries by s_load
-int pairs_build(const DevCsr<float>& in, int KC, int row_bytes, DevPairs& out);
-int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf);
-// stage 2, narrow (B <= 64): F[m][b] = sum_k W[m][k] * R[k][b]   (row-major operands, CSR streamed once)
-template <class T>
-int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf);
 
 // similarity producer of the reference's tutorial: weighted Jaccard between the rows of a feature matrix
 template <class T>

@@ -649,85 +649,11 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
   return SS_OK;
 }
 
-// ============================================================== stage 2, narrow: CSR streamed once
-// Wave per row.  Each lane loads one (index,value) of the row (coalesced 256-B requests), then the
-// wave replays them: LPN lanes share a non-zero and fetch B contiguous values of R's row, 64/LPN
-// non-zeros per step; partial sums of the 64/LPN groups are folded with __shfl_xor.
-template <class T, int VEC, int LPN>
-__global__ void __launch_bounds__(256) spmm_csr_narrow_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
-                                                              const T* __restrict__ val, int64_t M,
-                                                              const T* __restrict__ R, int64_t ldr, int B,
-                                                              T* __restrict__ F, int64_t ldf) {
-  constexpr int NPS = 64 / LPN;  // non-zeros per step
-  const int lane = threadIdx.x & 63;
-  const int g = lane / LPN;
-  const int c0 = (lane % LPN) * VEC;
-  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t m = wave0; m < M; m += nwaves) {
-    const int b = ptr[m], e = ptr[m + 1];
-    T acc[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = T(0);
-    for (int base = b; base < e; base += 64) {
-      const int x = base + lane;
-      const int kk = x < e ? idx[x] : 0;
-      const T vv = x < e ? val[x] : T(0);
-      const int cnt = (e - base < 64) ? (e - base) : 64;
-      if (LPN == 1) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i)
-          if (i < B) acc[i] = fma(vv, R[(int64_t)kk * ldr + i], acc[i]);
-      } else {
-        for (int i = 0; i < cnt; i += NPS) {
-          const int src = i + g;
-          const int k = __shfl(kk, src);
-          const T v = __shfl(vv, src);
-#pragma unroll
-          for (int j = 0; j < VEC; ++j)
-            if (c0 + j < B) acc[j] = fma(v, R[(int64_t)k * ldr + c0 + j], acc[j]);
-        }
-      }
-    }
-#pragma unroll
-    for (int o = LPN; o < 64; o <<= 1)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], o);
-    if (g == 0) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i)
-        if (c0 + i < B) F[m * ldf + c0 + i] = acc[i];
-    }
-  }
-}
-
-template <class T>
-int launch_spmm_csr_narrow(const DevCsr<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf) {
-  if (W.rows <= 0 || B <= 0) return SS_OK;
-  if (B > 64) return fail(SS_EINVAL, "narrow SpMM serves B <= 64 (got %d)", B);
-  path_add("spmm_csr_narrow");
-  const int block = 256;
-  const int grid = grid_1d(W.rows * 64, block, 256 * 32);
-#define SS_NARROW(VEC, LPN)                                                                          \
-  hipLaunchKernelGGL((spmm_csr_narrow_kernel<T, VEC, LPN>), dim3(grid), dim3(block), 0, ctx().stream, \
-                     W.ptr.p, W.idx.p, W.val.p, W.rows, R, ldr, B, F, ldf)
-  if (B == 1) SS_NARROW(1, 1);
-  else if (B == 2) SS_NARROW(2, 1);
-  else if (B <= 4) SS_NARROW(4, 1);
-  else if (B <= 8) SS_NARROW(4, 2);
-  else if (B <= 16) SS_NARROW(4, 4);
-  else if (B <= 32) SS_NARROW(4, 8);
-  else SS_NARROW(4, 16);
-#undef SS_NARROW
-  SS_LAUNCH_CHECK();
-  return SS_OK;
-}
-
 // ============================================================== stage 2, narrow, HBM-bound: R chunk in LDS
-// F = W*R for B <= 16 columns.  W is cut into column chunks of KC (all of R's rows k0..k0+KC for the B
+// F = W*R for B <= 4 columns.  W is cut into column chunks of KC (all of R's rows k0..k0+KC for the B
 // columns fit in LDS), stored chunk-major with 16-bit local indices, sub-rows padded to 4 entries so
 // that a lane streams 8 B of indices + 16 B of values per step; workgroup (c, slot) keeps chunk c of R
-// in LDS and walks every nslots-th group of 16 rows, one wave per sub-row, __shfl_xor to fold the lanes.
+// in LDS and strides over the rows, GL lanes per sub-row, __shfl_xor to fold the lanes.
 // Every non-zero of W is read exactly once from HBM (6 B instead of CSR's 8 B); partial sums per chunk
 // are combined in fixed order by narrow_reduce_kernel.
 template <class T>
@@ -746,11 +672,11 @@ struct NarrowArgs {
 
 constexpr int NARROW_THREADS = 1024;
 
-// GL = lanes that share one sub-row (64, 32, 16 or 8: the power of two above the mean sub-row length in
-// quads), so a wave streams 64/GL rows at once; UR row groups are unrolled to keep more loads in flight.
-template <class T, int VEC, int LPN, int GL, int UR, int NBQ>
+// VEC = columns (1, 2 or 4); GL = lanes that share one sub-row (64, 32, 16 or 8), so a wave streams 64/GL rows at once;
+// UR row groups per step; NBQ quads requested per lane and row.
+template <class T, int VEC, int GL, int UR, int NBQ>
 __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(NarrowArgs<T> a) {
-  constexpr int BV = VEC * LPN;
+  constexpr int BV = VEC;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);  // [KC + 1][BV]; row KC stays zero (padding target)
   using V = Vec<T, VEC>;
@@ -763,7 +689,7 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
   // 32-byte tile rows (two 16-byte halves per non-zero): all lanes fetch the same half at the same time, so with
   // a plain layout only every other 16-byte slot of the 256-byte LDS line is ever hit (a fixed 2-way conflict);
   // half h of row k is stored at h ^ ((k >> 3) & 1), which spreads random k over all 16 slots
-  constexpr bool SWZ = (LPN == 1) && (BV * sizeof(T) == 32);
+  constexpr bool SWZ = (BV * sizeof(T) == 32);
   constexpr int HB = 16 / (int)sizeof(T);  // values per 16-byte half
   for (int e = tid; e < (a.KC + 1) * BV; e += blockDim.x) {
     const int k = e / BV, b = e - k * BV;
@@ -788,7 +714,7 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
   };
 
   const int* __restrict__ off = a.off + (int64_t)c * a.M;
-  if (LPN == 1) {
+  {
     constexpr int RPS = 64 / GL;  // rows per wave-step
     const int sub = lane / GL, gl = lane % GL;
     const ushort4* __restrict__ ip = reinterpret_cast<const ushort4*>(a.idx);
@@ -916,69 +842,6 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
       step(mb, xb, xa);
       mb += stride;
     }
-  } else {
-    // LPN lanes share a non-zero (each fetches VEC of the BV columns); a group of GL lanes shares a row
-    constexpr int RPS = 64 / GL;
-    constexpr int EPS = GL / LPN;  // entries per group step
-    const int sub = lane / GL, gl = lane % GL;
-    const int e0 = gl / LPN;
-    const int c0 = (gl % LPN) * VEC;
-    const int64_t stride = (int64_t)nslots * nwaves * RPS * UR;
-    for (int64_t mb = ((int64_t)slot * nwaves + wave) * RPS * UR; mb < a.M; mb += stride) {
-      int xb[UR], xe[UR];
-      int kk[UR];
-      T vv[UR];
-      T acc[UR][VEC];
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        const int64_t m = mb + u * RPS + sub;
-        xb[u] = m < a.M ? off[m] * 4 : 0;
-        xe[u] = m < a.M ? off[m + 1] * 4 : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        const int x = xb[u] + e0;
-        const int xx = x < xe[u] ? x : xb[u];
-        kk[u] = a.idx[xx];
-        vv[u] = a.val[xx];
-      }
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[u][i] = T(0);
-        if (xb[u] + e0 < xe[u]) {
-          const V r = *reinterpret_cast<const V*>(&tile[kk[u] * BV + c0]);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[u][i] = fma(vv[u], r.v[i], acc[u][i]);
-        }
-        for (int x = xb[u] + e0 + EPS; x < xe[u]; x += EPS) {
-          const int k = a.idx[x];
-          const T v = a.val[x];
-          const V r = *reinterpret_cast<const V*>(&tile[k * BV + c0]);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[u][i] = fma(v, r.v[i], acc[u][i]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-#pragma unroll
-        for (int sft = LPN; sft < GL; sft <<= 1)
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[u][i] += __shfl_xor(acc[u][i], sft);
-        const int64_t m = mb + u * RPS + sub;
-        if (e0 == 0 && m < a.M) {
-          if (a.P) {
-            T* p = a.P + ((int64_t)c * a.M + m) * BV + c0;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) p[i] = acc[u][i];
-          } else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i)
-              if (c0 + i < a.B) a.F[m * a.ldf + c0 + i] = acc[u][i];
-          }
-        }
-      }
-    }
   }
 }
 
@@ -1003,15 +866,15 @@ int narrow_chunk_cols(int bv) {
   return (int)kc;
 }
 
-template <class T, int VEC, int LPN, int GL, int UR, int NBQ = 1>
+template <class T, int VEC, int GL, int UR, int NBQ = 1>
 static int launch_narrow_variant(const NarrowArgs<T>& a, unsigned grid, size_t lds) {
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR, NBQ>),
+    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_chunked_narrow_kernel<T, VEC, GL, UR, NBQ>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((spmm_chunked_narrow_kernel<T, VEC, LPN, GL, UR, NBQ>), dim3(grid), dim3(NARROW_THREADS), lds,
+  hipLaunchKernelGGL((spmm_chunked_narrow_kernel<T, VEC, GL, UR, NBQ>), dim3(grid), dim3(NARROW_THREADS), lds,
                      ctx().stream, a);
   SS_LAUNCH_CHECK();
   return SS_OK;
@@ -1028,27 +891,18 @@ constexpr int narrow_ur(int elem, int vec, int nbq) {
 }
 
 template <class T, int VEC>
-static int launch_narrow_lpn1(const NarrowArgs<T>& a, unsigned grid, size_t lds, double mean_quads) {
+static int launch_narrow_width(const NarrowArgs<T>& a, unsigned grid, size_t lds, double mean_quads) {
   constexpr int E = (int)sizeof(T);
   // GL lanes per row, one request per lane (two above 64 quads): the smallest capacity about 10 % above the mean
   // sub-row length in quads.  Measured (100k x 100k, 1 %): lanes past the end of a sub-row are not free (a step is
   // bound by the latency of its requests, so rows per step count: B = 4, mean 25 quads, 32 vs 64 lanes per row
   // 0.20 vs 0.35 ms), while the rolled tail for the few longer rows costs little
   const double need = 1.1 * mean_quads + 1.0;
-  if (need > 64.0) return launch_narrow_variant<T, VEC, 1, 64, narrow_ur(E, VEC, 2), 2>(a, grid, lds);
-  if (need > 32.0) return launch_narrow_variant<T, VEC, 1, 64, narrow_ur(E, VEC, 1)>(a, grid, lds);
-  if (need > 16.0) return launch_narrow_variant<T, VEC, 1, 32, narrow_ur(E, VEC, 1)>(a, grid, lds);
-  if (need > 8.0) return launch_narrow_variant<T, VEC, 1, 16, narrow_ur(E, VEC, 1)>(a, grid, lds);
-  return launch_narrow_variant<T, VEC, 1, 8, narrow_ur(E, VEC, 1)>(a, grid, lds);
-}
-
-// B = 8 / 16: group size so that a mean sub-row takes about two group steps
-template <class T, int LPN>
-static int launch_narrow_wide(const NarrowArgs<T>& a, unsigned grid, size_t lds, double mean_entries) {
-  const double steps64 = mean_entries / (64.0 / LPN);
-  if (steps64 > 2.0) return launch_narrow_variant<T, 4, LPN, 64, 2>(a, grid, lds);
-  if (steps64 > 1.0) return launch_narrow_variant<T, 4, LPN, 32, 4>(a, grid, lds);
-  return launch_narrow_variant<T, 4, LPN, 16, 4>(a, grid, lds);
+  if (need > 64.0) return launch_narrow_variant<T, VEC, 64, narrow_ur(E, VEC, 2), 2>(a, grid, lds);
+  if (need > 32.0) return launch_narrow_variant<T, VEC, 64, narrow_ur(E, VEC, 1)>(a, grid, lds);
+  if (need > 16.0) return launch_narrow_variant<T, VEC, 32, narrow_ur(E, VEC, 1)>(a, grid, lds);
+  if (need > 8.0) return launch_narrow_variant<T, VEC, 16, narrow_ur(E, VEC, 1)>(a, grid, lds);
+  return launch_narrow_variant<T, VEC, 8, narrow_ur(E, VEC, 1)>(a, grid, lds);
 }
 
 template <class T>
@@ -1077,13 +931,10 @@ int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64
   const double mean_quads = (double)W.stored / 4.0 / ((double)W.rows * (double)W.nchunks);
   int rc;
   switch (bv) {
-    case 1: rc = launch_narrow_lpn1<T, 1>(a, grid, lds, mean_quads); break;
-    case 2: rc = launch_narrow_lpn1<T, 2>(a, grid, lds, mean_quads); break;
-    case 4: rc = launch_narrow_lpn1<T, 4>(a, grid, lds, mean_quads); break;
-    case 8: rc = launch_narrow_lpn1<T, 8>(a, grid, lds, mean_quads); break;
-    case 16: rc = getenv("SS_NARROW_LPN") ? launch_narrow_wide<T, 4>(a, grid, lds, mean_quads * 4.0)
-                                          : launch_narrow_lpn1<T, 16>(a, grid, lds, mean_quads); break;
-    default: return fail(SS_EINVAL, "narrow width must be 1, 2, 4, 8 or 16");
+    case 1: rc = launch_narrow_width<T, 1>(a, grid, lds, mean_quads); break;
+    case 2: rc = launch_narrow_width<T, 2>(a, grid, lds, mean_quads); break;
+    case 4: rc = launch_narrow_width<T, 4>(a, grid, lds, mean_quads); break;
+    default: return fail(SS_EINVAL, "narrow width must be 1, 2 or 4");
   }
   SS_TRY(rc);
   if (W.nchunks > 1) {
@@ -1091,106 +942,6 @@ int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64
                        W.nchunks, W.rows, bv, B, F, ldf);
     SS_LAUNCH_CHECK();
   }
-  return SS_OK;
-}
-
-// ============================================================== stage 2, 16 < B <= 64: accumulators in registers
-// F = W*R with lane = column of R/F.  A wave owns up to RA_NV consecutive rows of W, one accumulator
-// register per row; the workgroup walks the column chunks of W, keeps the chunk's rows of R in LDS
-// ([KC][64] floats, all 160 KB) and every entry (tile row offset, value) is a scalar pair (s_load)
-// followed by one conflict-free ds_read_b32 and one FMA across the 64 columns.  No partial sums ever
-// leave the registers; W is read once (chunk-major), R once per workgroup.
-struct RegAccArgs {
-  const int* off;
-  const uint2* ent;
-  int64_t M, K;
-  int KC, nchunks, B;
-  int rpw;  // rows per wave (<= RA_NV)
-  const float* R;
-  int64_t ldr;
-  float* F;
-  int64_t ldf;
-};
-constexpr int RA_NV = 32;
-constexpr int RA_THREADS = 1024;
-
-__global__ void __launch_bounds__(RA_THREADS) spmm_regacc_kernel(RegAccArgs a) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  float* tile = reinterpret_cast<float*>(smem_raw);  // [KC][64]
-  const char* tb = reinterpret_cast<const char*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int64_t r0 = ((int64_t)blockIdx.x * nwaves + wave) * a.rpw;
-  int nr = 0;
-  if (r0 < a.M) nr = (int)((a.M - r0 < a.rpw) ? (a.M - r0) : a.rpw);
-  nr = __builtin_amdgcn_readfirstlane(nr);
-  float acc[RA_NV];
-#pragma unroll
-  for (int j = 0; j < RA_NV; ++j) acc[j] = 0.0f;
-  const uint2* __restrict__ ent = a.ent;
-  const int lane4 = lane * 4;
-
-  for (int c = 0; c < a.nchunks; ++c) {
-    const int64_t k0 = (int64_t)c * a.KC;
-    const int kn = (int)((a.K - k0 < a.KC) ? (a.K - k0) : a.KC);
-    if (c) __syncthreads();
-    for (int e = tid; e < a.KC * 64; e += blockDim.x) {
-      const int k = e >> 6, b = e & 63;
-      tile[e] = (k < kn && b < a.B) ? a.R[(k0 + k) * a.ldr + b] : 0.0f;
-    }
-    __syncthreads();
-    int offv = 0;
-    if (lane <= nr && nr > 0) offv = a.off[(int64_t)c * a.M + r0 + lane];
-#pragma unroll
-    for (int j = 0; j < RA_NV; ++j) {
-      if (j < nr) {
-        const int b = __builtin_amdgcn_readlane(offv, j);
-        const int e = __builtin_amdgcn_readlane(offv, j + 1);
-        for (int x = b; x < e; x += 4) {
-          const uint2 q0 = ent[x], q1 = ent[x + 1], q2 = ent[x + 2], q3 = ent[x + 3];  // 8 entries of slack at the end
-          const float w0 = __uint_as_float(q0.y);
-          const float w1 = x + 1 < e ? __uint_as_float(q1.y) : 0.0f;
-          const float w2 = x + 2 < e ? __uint_as_float(q2.y) : 0.0f;
-          const float w3 = x + 3 < e ? __uint_as_float(q3.y) : 0.0f;
-          // offsets of entries past the row end belong to the next row of the same chunk (or the zero slack):
-          // always inside the tile
-          const float t0 = *reinterpret_cast<const float*>(tb + q0.x + lane4);
-          const float t1 = *reinterpret_cast<const float*>(tb + q1.x + lane4);
-          const float t2 = *reinterpret_cast<const float*>(tb + q2.x + lane4);
-          const float t3 = *reinterpret_cast<const float*>(tb + q3.x + lane4);
-          acc[j] = fmaf(w0, t0, acc[j]);
-          acc[j] = fmaf(w1, t1, acc[j]);
-          acc[j] = fmaf(w2, t2, acc[j]);
-          acc[j] = fmaf(w3, t3, acc[j]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < RA_NV; ++j)
-    if (j < nr && lane < a.B) a.F[(r0 + j) * a.ldf + lane] = acc[j];
-}
-
-int launch_spmm_regacc(const DevPairs& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf) {
-  if (W.rows <= 0 || B <= 0) return SS_OK;
-  if (B > 64 || W.row_bytes != 256) return fail(SS_EINVAL, "register-accumulator SpMM serves B <= 64");
-  path_add("spmm_regacc");
-  RegAccArgs a{};
-  a.off = W.off.p; a.ent = W.ent.p; a.M = W.rows; a.K = W.cols; a.KC = W.KC; a.nchunks = W.nchunks; a.B = B;
-  a.R = R; a.ldr = ldr; a.F = F; a.ldf = ldf;
-  const int nw = RA_THREADS / 64;
-  int64_t rpw = ceil_div(ceil_div(W.rows, ctx().num_cu), nw);
-  if (rpw > RA_NV) rpw = RA_NV;
-  if (rpw < 1) rpw = 1;
-  a.rpw = (int)rpw;
-  const unsigned grid = (unsigned)ceil_div(W.rows, rpw * nw);
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_regacc_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(spmm_regacc_kernel, dim3(grid), dim3(RA_THREADS), (size_t)W.KC * 256, ctx().stream, a);
-  SS_LAUNCH_CHECK();
   return SS_OK;
 }
 
@@ -1526,7 +1277,6 @@ int launch_jaccard(const T* F, int64_t n, int64_t d, int64_t ld, T* S, int64_t l
   template int sell_max_chunk<T>(int);                                                                      \
   template int launch_spmm_sell<T>(const DevSell<T>&, const T*, int64_t, int64_t, T*, int64_t, const int*,  \
                                    const int*);                                                             \
-  template int launch_spmm_csr_narrow<T>(const DevCsr<T>&, const T*, int64_t, int, T*, int64_t);            \
   template int narrow_chunk_cols<T>(int);                                                                   \
   template int launch_spmm_chunked_narrow<T>(const DevChunked<T>&, int, const T*, int64_t, int, T*, int64_t, \
                                              DevBuf<T>&);                                                   \

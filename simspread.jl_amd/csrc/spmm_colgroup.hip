@@ -1,14 +1,14 @@
-// Stage 2, mid width (16 <= B <= 64 columns of R, fp32; 8 <= B <= 32, fp64): F = W*R with a 2-D cut of the work
-// and bank-conflict-free gathers.
+// Stage 2, mid width (5 <= B columns of R, B * sizeof(T) <= 256 bytes: fp32 B <= 64, fp64 B <= 32): F = W*R with a 2-D
+// cut of the work and bank-conflict-free gathers.
 //
-// The row-block kernel (spmm_mid.hip) gives every CU its own rows and makes it walk ALL chunks of R, so R is
-// restaged 256 times (B = 64, K = 100k: 6.5 GB of L2 -> LDS traffic for a 0.85 GB problem), and its lanes gather
-// rows of the tile at random 16-byte slots (2.5-3 LDS cycles per ds_read_b128 instead of 1).  Here
+// A kernel that gives every CU its own rows and makes it walk ALL chunks of R (the row-block kernel this one replaced,
+// DESIGN.md 4.3) restages R 256 times (B = 64, K = 100k: 6.5 GB of L2 -> LDS traffic for a 0.85 GB problem), and lanes
+// that gather rows of the tile at random 16-byte slots pay 2.5-3 LDS cycles per ds_read_b128 instead of 1.  Here
 //
 //  * the grid is RB row blocks x CG chunk groups: workgroup (rb, cg) owns rows_per_wg rows (accumulators in
 //    registers for as many rows as the register file holds: 8 waves x NP x 16 rows) and walks only the chunks
 //    c = cg, cg + CG, ...; R is restaged RB times instead of 256, and the CG partial sums per row are combined
-//    in fixed order by narrow_reduce_kernel (CG = 1: written directly).  RB and CG are chosen per launch so that
+//    in fixed order by colgroup_reduce_kernel (CG = 1: written directly).  RB and CG are chosen per launch so that
 //    RB*CG fills the CUs and RB*|R| + 2*CG*|F| is smallest;
 //  * four lanes share a non-zero and a wave works on 16 rows at once (lane group j = lane / 4, row = base + j).
 //    The tile row of a non-zero (ROWB = 64, 128 or 256 bytes) is read as NR = ROWB/64 ds_read_b128 per lane.
@@ -38,13 +38,13 @@ struct ColArgs {
   const T* val;
   int64_t M, K;
   int KC, nchunks, B;
+  int BR;      // columns present in the R buffer (B, or the tile width when R was padded for 16-byte staging)
   const T* R;  // row-major [K][ldr]
   int64_t ldr;
   T* F;        // row-major [M][ldf]; used when CG == 1
   int64_t ldf;
   T* P;        // [CG][M][BV] partial sums when CG > 1
   int rows_per_wg, RBn, CG, np_used;
-  int vec_ok;
 };
 
 __device__ __attribute__((aligned(16))) unsigned int col_zero[4] = {0u, 0u, 0u, 0u};
@@ -181,27 +181,16 @@ __global__ void __launch_bounds__(WAVES * 64) spmm_colgroup_kernel(ColArgs<T> a)
     // LDS-DMA: a wave instruction fills 64 consecutive pieces of the tile; pieces outside R read a zero word
     const unsigned char* rbase = reinterpret_cast<const unsigned char*>(a.R + k0 * a.ldr);
     const int64_t rowstride = a.ldr * (int64_t)sizeof(T);
-    if (a.vec_ok) {
+    {
+      // rows of R arrive in 16-byte pieces (the launcher pads R when B, the leading dimension or the base address do not allow it)
       const int pieces = (a.KC + 1) * NCG;
-      const int bslots = a.B / PW;
+      const int bslots = a.BR / PW;
       for (int base = (tid >> 6) * 64; base < pieces; base += COL_THREADS) {
         const int pc = base + (tid & 63);
         if (pc < pieces) {
           const int k = pc / NCG, slot = pc % NCG;
           const void* src = (k < kn && slot < bslots) ? (const void*)(rbase + k * rowstride + slot * 16) : (const void*)col_zero;
           __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(tb + (size_t)base * 16), 16, 0, 0);
-        }
-      }
-    } else {
-      constexpr int WPR = ROWB / 4;
-      const int words = (a.KC + 1) * WPR;
-      const int bwords = a.B * ((int)sizeof(T) / 4);
-      for (int base = (tid >> 6) * 64; base < words; base += COL_THREADS) {
-        const int pc = base + (tid & 63);
-        if (pc < words) {
-          const int k = pc / WPR, wc = pc % WPR;
-          const void* src = (k < kn && wc < bwords) ? (const void*)(rbase + k * rowstride + wc * 4) : (const void*)col_zero;
-          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(tb + (size_t)base * 4), 4, 0, 0);
         }
       }
     }
@@ -315,6 +304,19 @@ __global__ void colgroup_reduce_kernel(const T* __restrict__ P, int CG, int64_t 
   }
 }
 
+// R rows that cannot be moved in 16-byte pieces (B or the leading dimension no multiple of 16 bytes, or a misaligned
+// base): one pass copies them into [K][BV] rows padded with zeros -- K*BV values, against the 4x as many 4-byte LDS-DMA
+// instructions of every restaging otherwise (measured, fp32 B = 9: 0.27 -> 0.23 ms)
+template <class T>
+__global__ void colgroup_pad_rows_kernel(const T* __restrict__ R, int64_t ldr, int64_t K, int B, int BV, T* __restrict__ out) {
+  const int64_t total = K * BV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i / BV;
+    const int b = (int)(i - k * BV);
+    out[i] = b < B ? R[k * ldr + b] : T(0);
+  }
+}
+
 template <class T, int BV, int NP, bool BIN, int WAVES>
 static int launch_col_variant(const ColArgs<T>& a, unsigned grid, size_t lds) {
   static std::atomic<bool> attr_set{false};
@@ -367,9 +369,9 @@ int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr
   ColArgs<T> a{};
   a.off = W.off.p; a.idx = W.idx.p; a.val = W.val.p;
   a.M = W.rows; a.K = W.cols; a.KC = W.SC; a.nchunks = W.nchunks; a.B = B;
-  a.R = R; a.ldr = ldr; a.F = F; a.ldf = ldf;
+  a.R = R; a.ldr = ldr; a.F = F; a.ldf = ldf; a.BR = B;
   constexpr int PW = 16 / (int)sizeof(T);
-  a.vec_ok = (ldr % PW == 0 && B % PW == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0) ? 1 : 0;
+  const bool vec_ok = (ldr % PW == 0 && B % PW == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0);
 
   // the cut: RB row blocks x CG chunk groups.  A workgroup holds 8 waves * NP * 16 rows (accumulators in registers);
   // RB follows from the row count, CG fills the CUs with one resident round (more chunk groups = more partial sums,
@@ -388,10 +390,20 @@ int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr
   }
   a.CG = cgn;
   a.P = nullptr;
-  if (a.CG > 1) {
-    const size_t need = (size_t)a.CG * (size_t)W.rows * (size_t)bv;
-    if (partial.n < need) SS_TRY(partial.alloc(need));
-    a.P = partial.p;
+  // scratch: the CG partial sums, then (rows of R not movable in 16-byte pieces) the padded copy of R
+  const size_t need_p = a.CG > 1 ? (size_t)a.CG * (size_t)W.rows * (size_t)bv : 0;
+  const size_t need_r = vec_ok ? 0 : (size_t)W.cols * (size_t)bv;
+  if (partial.n < need_p + need_r) SS_TRY(partial.alloc(need_p + need_r));
+  if (a.CG > 1) a.P = partial.p;
+  if (!vec_ok) {
+    T* rp = partial.p + need_p;   // 16-byte aligned: need_p is a multiple of bv values
+    if (W.cols > 0) {
+      int64_t g = ceil_div(W.cols * (int64_t)bv, 256);
+      if (g > 256 * 16) g = 256 * 16;
+      hipLaunchKernelGGL(colgroup_pad_rows_kernel<T>, dim3((unsigned)g), dim3(256), 0, ctx().stream, R, ldr, W.cols, B, bv, rp);
+      SS_LAUNCH_CHECK();
+    }
+    a.R = rp; a.ldr = bv; a.BR = bv;
   }
   const unsigned grid = (unsigned)(a.RBn * a.CG);
   if (getenv("SS_COL_DEBUG"))
@@ -422,7 +434,7 @@ int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr
   if (a.CG > 1) {
     int64_t g = ceil_div(W.rows * bv, 256);
     if (g > 256 * 16) g = 256 * 16;
-    hipLaunchKernelGGL(colgroup_reduce_kernel<T>, dim3((unsigned)g), dim3(256), 0, ctx().stream, partial.p, a.CG, W.rows,
+    hipLaunchKernelGGL(colgroup_reduce_kernel<T>, dim3((unsigned)g), dim3(256), 0, ctx().stream, a.P, a.CG, W.rows,
                        bv, B, F, ldf);
     SS_LAUNCH_CHECK();
   }

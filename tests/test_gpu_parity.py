@@ -473,13 +473,11 @@ def test_spmm_empty_rows_long_rows_and_multichunk(monkeypatch):
     monkeypatch.setenv("SS_NARROW_CHUNK", "700")
     w = ss.DeviceSpMat(W, dtype=np.float64)
     assert_close(w.spmm(R), W @ R, np.float64)
-    for B in (1, 2, 5, 8, 16):    # narrow kernel (B <= 8: 8 chunks, partial sums combined in order) / row-block kernel
+    for B in (1, 2, 5, 8, 16):    # narrow kernel (B <= 4: 8 chunks, partial sums combined in order) / 2-D kernel
         assert_close(w.spmm(R[:, :B].copy()), W @ R[:, :B], np.float64)
     w32 = ss.DeviceSpMat(W, dtype=np.float32)
-    for B in (1, 4, 8, 9, 17, 32, 40, 64):   # 8..32: row-block kernel over 8 LDS chunks of R; wider: SELL kernel
+    for B in (1, 4, 8, 9, 17, 32, 40, 64):   # 5..64: 2-D kernel over 8 LDS chunks of R
         assert_close(w32.spmm(R[:, :B].astype(np.float32)), W @ R[:, :B], np.float32)
-    monkeypatch.setenv("SS_NARROW_CSR", "1")   # the L2-gather CSR kernel (what 16 < B <= 64 uses)
-    assert_close(w.spmm(R[:, :5].copy()), W @ R[:, :5], np.float64)
     # skewed rows: split the long rows into virtual rows, sort by length, put the scores back in order
     monkeypatch.setenv("SS_SELL_SORT", "1")
     monkeypatch.setenv("SS_SELL_LMAX", "256")
@@ -515,10 +513,10 @@ def test_spmm_narrow_every_group_size(mean_entries, dtype):
 @pytest.mark.parametrize("dtype,B", [(np.float32, 12), (np.float32, 16), (np.float32, 28), (np.float32, 64), (np.float32, 52),
                                      (np.float64, 6), (np.float64, 16), (np.float64, 32)])
 def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
-    """Mid width (fp32 9 <= B <= 64, fp64 5 <= B <= 32): the 2-D kernel (spmm_colgroup.hip).  Several row blocks,
+    """Mid width (fp32 5 <= B <= 64, fp64 5 <= B <= 32): the 2-D kernel (spmm_colgroup.hip).  Several row blocks,
     several chunk groups (partial sums combined in fixed order), several LDS chunks of R per group, sub-rows longer
-    than the prefetched batches (row 7 is full) and empty rows; must agree with scipy and with the row-block / wide
-    kernels, and be bitwise repeatable."""
+    than the prefetched batches (row 7 is full) and empty rows; must agree with scipy and with the SELL kernel, and
+    be bitwise repeatable."""
     rng = np.random.default_rng(100 + B)
     M, K = 9011, 2900
     W = sp.random(M, K, density=0.012, format="lil", random_state=rng, dtype=np.float64)
@@ -542,10 +540,13 @@ def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
     assert_close_signed(ss.DeviceSpMat(W.astype(dtype), dtype=dtype).spmm(R.astype(dtype)), want, dtype)
 
 
-@pytest.mark.parametrize("dtype,B", [(np.float32, 16), (np.float32, 24), (np.float32, 50), (np.float64, 12), (np.float64, 32)])
-def test_spmm_mid_width_row_blocks(dtype, B, monkeypatch):
-    """8 < B <= 32 (fp64: 16): row-block kernel (spmm_mid.hip) with several rows per lane group and several LDS
-    chunks of R (wider cases take the wide kernel); SS_MID=0 (the wide kernel) must agree to rounding."""
+@pytest.mark.parametrize("dtype,B", [(np.float32, 5), (np.float32, 7), (np.float32, 9), (np.float32, 16), (np.float32, 24),
+                                     (np.float32, 50), (np.float64, 5), (np.float64, 12), (np.float64, 31)])
+def test_spmm_width_routing(dtype, B, monkeypatch):
+    """Row-major operands: B <= 4 narrow kernel, 5 <= B (B * sizeof <= 256 bytes) the 2-D kernel, wider the SELL kernel.
+    Widths that cannot be staged in 16-byte pieces (B = 5, 7, 9, 31; a leading dimension that is no multiple of 16
+    bytes) go through the padded copy of R; SS_COL=0 (SELL kernel) must agree to rounding; results are bitwise
+    repeatable (fixed summation order)."""
     rng = np.random.default_rng(B)
     M, K = 30011, 2900
     W = sp.random(M, K, density=0.012, format="csr", random_state=rng, dtype=np.float64)
@@ -555,10 +556,17 @@ def test_spmm_mid_width_row_blocks(dtype, B, monkeypatch):
     monkeypatch.setenv("SS_NARROW_CHUNK", "600")     # 5 chunks of R
     w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
     got = w.spmm(R.astype(dtype))
+    assert "spmm_colgroup" in ss.path_last()
     assert_close_signed(got, want, dtype)
-    assert np.array_equal(got, w.spmm(R.astype(dtype)))          # fixed summation order: bitwise repeatable
-    monkeypatch.setenv("SS_MID", "0")
-    assert_close_signed(ss.DeviceSpMat(W.astype(dtype), dtype=dtype).spmm(R.astype(dtype)), want, dtype)
+    assert np.array_equal(got, w.spmm(R.astype(dtype)))
+    for b, name in ((4, "spmm_chunked_narrow"), (3, "spmm_chunked_narrow"), (80, "spmm_sell")):
+        Rb = rng.standard_normal((K, b))
+        assert_close_signed(w.spmm(Rb.astype(dtype)), W @ Rb, dtype)
+        assert any(name in k for k in ss.path_last())
+    monkeypatch.setenv("SS_COL", "0")
+    w0 = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
+    assert_close_signed(w0.spmm(R.astype(dtype)), want, dtype)
+    assert any("spmm_sell" in k for k in ss.path_last())
 
 
 def test_power_law_graph_predict_with_sorted_split_operand(monkeypatch):
