@@ -80,7 +80,7 @@ def csr_bytes(nnz, rows, vb=4):
 
 def spmm_sweep(ss, torch, steps=5):
     """Narrow-R regime of the W*R SpMM at the north-star size: W 100k x 100k, 1 % (nnz ~1e8), fp32,
-    B in {1,4,8,16,32,64}; HBM roofline fraction on algorithmic bytes (CSR at 8 B/nnz) and on the
+    B in {1,2,4,8,16,32,64}; HBM roofline fraction on algorithmic bytes (CSR at 8 B/nnz) and on the
     bytes the kernels really stream (chunk-major operand: 2-byte local index + 4-byte value = 6 B/nnz)."""
     import ctypes as C
     from simspread_jl_amd import _lib as L
@@ -107,7 +107,7 @@ def spmm_sweep(ss, torch, steps=5):
     h = C.c_void_p()
     L.check(lib.ss_spmat_create_csr_f32(M, K, ptr.data_ptr(), idx.data_ptr(), val.data_ptr(), 0, L.SS_MEM_DEVICE, C.byref(h)))
     out = []
-    widths = tuple(int(x) for x in os.environ.get("SWEEP_B", "1,4,8,16,32,64").split(","))
+    widths = tuple(int(x) for x in os.environ.get("SWEEP_B", "1,2,4,8,16,32,64").split(","))
     for B in widths:
         R = torch.rand(K, B, device=dev, dtype=torch.float32, generator=g)
         F = torch.empty(M, B, device=dev, dtype=torch.float32)
