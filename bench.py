@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0 # ibid.: what streaming kernels reach (SURVEY.md 8d asks for the fraction of this too)
 FP32_PEAK_TFLOPS = 157.3    # fp32 vector == fp32-input MFMA peak
 
 
@@ -122,11 +123,13 @@ def spmm_sweep(ss, torch, steps=5):
         streamed = nnz * 6 + K * B * 4 + M * B * 4
         out.append({"B": B, "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
                     "frac_hbm": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "bytes": by,
-                    "frac_hbm_streamed": round(streamed / t / 1e9 / HBM_PEAK_GBS, 4), "kernel": ",".join(ss.path_last())})
+                    "frac_hbm_streamed": round(streamed / t / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_hbm_achievable": round(by / t / 1e9 / HBM_ACHIEVABLE_GBS, 4), "kernel": ",".join(ss.path_last())})
     lib.ss_spmat_destroy(h)
     return {"workload": f"W 100k x 100k, 1 percent dense (nnz {nnz}), fp32, CSR streamed once from HBM",
             "frac_hbm": "algorithmic bytes (CSR 8 B/nnz + R + F) / time / 8 TB/s",
             "frac_hbm_streamed": "bytes of the chunk-major operand the kernels read (6 B/nnz + R + F) / time / 8 TB/s",
+            "frac_hbm_achievable": "algorithmic bytes / time / 6.3 TB/s (the achievable rate MI355X_MICROARCH.md quotes; SURVEY.md 8d)",
             "results": out}
 
 
@@ -420,7 +423,7 @@ def main():
             "kernel": "transfer_kernel<%s> (stage 1, T = (Xq Df^-1) Xs' Ds^-1; %d%% of the step)"
                       % (tname, round(100 * transfer_ms / max(transfer_ms + spmm_ms, 1e-9))),
             "bound": "hbm", "achieved": round(s1_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(s1_gbps / HBM_PEAK_GBS, 4),
+            "frac": round(s1_gbps / HBM_PEAK_GBS, 4), "frac_of_achievable_6p3TBps": round(s1_gbps / HBM_ACHIEVABLE_GBS, 4),
             "traffic": s1_pmc["hbm_bytes_per_launch"] if s1_pmc else None, "traffic_source": s1_src,
             "avg_launch_ms": round(transfer_ms, 4), "algorithmic_bytes": s1_bytes,
             "flops": s1_flops, "frac_fp32_fma": round(s1_flops / (transfer_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
