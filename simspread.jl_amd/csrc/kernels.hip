@@ -845,17 +845,21 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
   }
 }
 
-template <class T>
-__global__ void narrow_reduce_kernel(const T* __restrict__ P, int nchunks, int64_t M, int BV, int B, T* __restrict__ F,
+// F[m][0..B) = sum of the per-chunk partial sums, in chunk order (one thread per row: BV <= 4 values)
+template <class T, int BV>
+__global__ void narrow_reduce_kernel(const T* __restrict__ P, int nchunks, int64_t M, int B, T* __restrict__ F,
                                      int64_t ldf) {
-  const int64_t total = M * BV;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / BV;
-    const int b = (int)(i - m * BV);
-    if (b >= B) continue;
-    T s = T(0);
-    for (int c = 0; c < nchunks; ++c) s += P[(int64_t)c * total + i];
-    F[m * ldf + b] = s;
+  using PV = Vec<T, BV>;
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    PV s = *reinterpret_cast<const PV*>(P + m * BV);
+    for (int c = 1; c < nchunks; ++c) {
+      const PV t = *reinterpret_cast<const PV*>(P + ((int64_t)c * M + m) * BV);
+#pragma unroll
+      for (int e = 0; e < BV; ++e) s.v[e] += t.v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < BV; ++e)
+      if (e < B) F[m * ldf + e] = s.v[e];
   }
 }
 
@@ -938,8 +942,12 @@ int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64
   }
   SS_TRY(rc);
   if (W.nchunks > 1) {
-    hipLaunchKernelGGL(narrow_reduce_kernel<T>, dim3(grid_1d(W.rows * bv, 256)), dim3(256), 0, ctx().stream, partial.p,
-                       W.nchunks, W.rows, bv, B, F, ldf);
+    const dim3 rg(grid_1d(W.rows, 256)), rb(256);
+    switch (bv) {
+      case 1: hipLaunchKernelGGL((narrow_reduce_kernel<T, 1>), rg, rb, 0, ctx().stream, partial.p, W.nchunks, W.rows, B, F, ldf); break;
+      case 2: hipLaunchKernelGGL((narrow_reduce_kernel<T, 2>), rg, rb, 0, ctx().stream, partial.p, W.nchunks, W.rows, B, F, ldf); break;
+      default: hipLaunchKernelGGL((narrow_reduce_kernel<T, 4>), rg, rb, 0, ctx().stream, partial.p, W.nchunks, W.rows, B, F, ldf); break;
+    }
     SS_LAUNCH_CHECK();
   }
   return SS_OK;

@@ -290,17 +290,31 @@ __global__ void __launch_bounds__(WAVES * 64) spmm_colgroup_kernel(ColArgs<T> a)
   }
 }
 
-template <class T>
+// F[m][0..B) = sum over the CG partial sums, in chunk-group order.  One thread per 16-byte piece of a row (BV is a
+// multiple of the piece), 32-bit index arithmetic (M * BV < 2^31 is checked by the launcher; else the 64-bit variant).
+template <class T, class I>
 __global__ void colgroup_reduce_kernel(const T* __restrict__ P, int CG, int64_t M, int BV, int B, T* __restrict__ F,
                                        int64_t ldf) {
-  const int64_t total = M * BV;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / BV;
-    const int b = (int)(i - m * BV);
+  constexpr int PW = 16 / (int)sizeof(T);
+  using P4 = ColPack<T, PW>;
+  const I ppr = (I)(BV / PW);                 // pieces per row
+  const I total = (I)M * ppr;
+  const I stride = (I)gridDim.x * blockDim.x;
+  const int64_t plane = M * (int64_t)BV;
+  for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const I m = i / ppr;
+    const int b = (int)(i - m * ppr) * PW;
     if (b >= B) continue;
-    T s = T(0);
-    for (int c = 0; c < CG; ++c) s += P[(int64_t)c * total + i];
-    F[m * ldf + b] = s;
+    P4 s = *reinterpret_cast<const P4*>(P + (int64_t)i * PW);
+    for (int c = 1; c < CG; ++c) {
+      const P4 t = *reinterpret_cast<const P4*>(P + (int64_t)c * plane + (int64_t)i * PW);
+#pragma unroll
+      for (int e = 0; e < PW; ++e) s.v[e] += t.v[e];
+    }
+    T* f = F + (int64_t)m * ldf + b;
+#pragma unroll
+    for (int e = 0; e < PW; ++e)
+      if (b + e < B) f[e] = s.v[e];
   }
 }
 
@@ -432,10 +446,15 @@ int launch_spmm_colgroup(const DevChunked<T>& W, int bv, const T* R, int64_t ldr
 #undef SS_COL
   SS_TRY(rc);
   if (a.CG > 1) {
-    int64_t g = ceil_div(W.rows * bv, 256);
+    const int64_t pieces = W.rows * (int64_t)(bv / PW);
+    int64_t g = ceil_div(pieces, 256);
     if (g > 256 * 16) g = 256 * 16;
-    hipLaunchKernelGGL(colgroup_reduce_kernel<T>, dim3((unsigned)g), dim3(256), 0, ctx().stream, a.P, a.CG, W.rows,
-                       bv, B, F, ldf);
+    if (pieces < (1LL << 31))
+      hipLaunchKernelGGL((colgroup_reduce_kernel<T, unsigned>), dim3((unsigned)g), dim3(256), 0, ctx().stream, a.P, a.CG,
+                         W.rows, bv, B, F, ldf);
+    else
+      hipLaunchKernelGGL((colgroup_reduce_kernel<T, int64_t>), dim3((unsigned)g), dim3(256), 0, ctx().stream, a.P, a.CG,
+                         W.rows, bv, B, F, ldf);
     SS_LAUNCH_CHECK();
   }
   return SS_OK;
