@@ -691,11 +691,43 @@ __global__ void __launch_bounds__(NARROW_THREADS) spmm_chunked_narrow_kernel(Nar
   // half h of row k is stored at h ^ ((k >> 3) & 1), which spreads random k over all 16 slots
   constexpr bool SWZ = (BV * sizeof(T) == 32);
   constexpr int HB = 16 / (int)sizeof(T);  // values per 16-byte half
-  for (int e = tid; e < (a.KC + 1) * BV; e += blockDim.x) {
-    const int k = e / BV, b = e - k * BV;
-    const T v = (k < kn && b < a.B) ? a.R[(k0 + k) * a.ldr + b] : T(0);
-    if constexpr (SWZ) tile[k * BV + ((((b / HB) ^ (k >> 3)) & 1) * HB) + (b % HB)] = v;
-    else tile[e] = v;
+  // rows of R packed without gaps (ldr == B == BV) and a 16-byte aligned chunk: the tile is a plain copy, moved in
+  // 16-byte pieces (KC is a multiple of 4 by construction); otherwise element by element
+  constexpr int PW16 = 16 / (int)sizeof(T);
+  const bool packed = a.ldr == BV && a.B == BV &&
+                      ((reinterpret_cast<uintptr_t>(a.R + k0 * a.ldr) & 15) == 0) && ((a.KC * BV) % PW16 == 0);
+  if (packed) {
+    using P16 = Vec<T, PW16>;
+    const P16* __restrict__ src = reinterpret_cast<const P16*>(a.R + k0 * a.ldr);
+    P16* dst = reinterpret_cast<P16*>(tile);
+    const int npieces = ((a.KC + 1) * BV + PW16 - 1) / PW16, nfull = (kn * BV) / PW16;
+    for (int i = tid; i < npieces; i += blockDim.x) {
+      P16 v;
+      if (i < nfull) {
+        v = src[i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < PW16; ++e) {
+          const int x = i * PW16 + e;   // element of the tile; row x / BV
+          v.v[e] = (x < kn * BV) ? a.R[k0 * a.ldr + x] : T(0);
+        }
+      }
+      if ((i + 1) * PW16 <= (a.KC + 1) * BV) {
+        // 32-byte tile rows: half h of row k sits at h ^ ((k >> 3) & 1) (see below), i.e. piece i at i ^ ((i >> 4) & 1)
+        dst[SWZ ? (i ^ ((i >> 4) & 1)) : i] = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < PW16; ++e)
+          if (i * PW16 + e < (a.KC + 1) * BV) tile[i * PW16 + e] = v.v[e];
+      }
+    }
+  } else {
+    for (int e = tid; e < (a.KC + 1) * BV; e += blockDim.x) {
+      const int k = e / BV, b = e - k * BV;
+      const T v = (k < kn && b < a.B) ? a.R[(k0 + k) * a.ldr + b] : T(0);
+      if constexpr (SWZ) tile[k * BV + ((((b / HB) ^ (k >> 3)) & 1) * HB) + (b % HB)] = v;
+      else tile[e] = v;
+    }
   }
   __syncthreads();
   auto tile_row = [&](int k) __attribute__((always_inline)) {
@@ -867,6 +899,7 @@ template <class T>
 int narrow_chunk_cols(int bv) {
   int64_t kc = (int64_t)(160 * 1024) / ((int64_t)bv * (int64_t)sizeof(T)) - 1;
   if (kc > 65535) kc = 65535;
+  kc &= ~3LL;  // chunks of R start on 16-byte boundaries (vector staging of the tile)
   return (int)kc;
 }
 
