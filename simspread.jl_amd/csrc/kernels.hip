@@ -449,6 +449,7 @@ struct SellArgs {
 
 constexpr int SELL_THREADS = 1024;
 constexpr int SELL_NB = 4;  // quads of W in flight per lane ahead of the gathers
+constexpr int SELL_STAGE_IT = 5;  // passes of SELL_THREADS per staging round (the largest tile, 10240 rows, takes two rounds)
 
 // Workgroup = QT columns of R (QT queries).  Per chunk of KC columns of W: the tile
 // R[b0..b0+QT)[k0..k0+KC) sits in LDS as [k][QT] so that one ds_read_b128 fetches the QT
@@ -481,12 +482,32 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
     const int64_t k0 = (int64_t)c * a.KC;
     const int kn = (int)((a.K - k0 < a.KC) ? (a.K - k0) : a.KC);
     if (c) __syncthreads();
-    for (int k = tid; k <= a.KC; k += blockDim.x) {
-      V v;
+    // Stage the tile in rounds of SELL_STAGE_IT passes of 1024 threads: all loads of a round are requested before its
+    // first LDS write (clamped, branch-free addresses) -- one memory latency per round (two for the largest tile)
+    // instead of one per pass.  Nothing else runs on the CU meanwhile (one workgroup per CU): this latency is not hidden.
+    for (int kb = 0; kb <= a.KC; kb += SELL_STAGE_IT * SELL_THREADS) {
+      T stg[SELL_STAGE_IT][QT];
+      const int klast = kn > 0 ? kn - 1 : 0;
 #pragma unroll
-      for (int q = 0; q < QT; ++q)
-        v.v[q] = (k < kn && b0 + q < a.B) ? a.R[(b0 + q) * a.ldr + k0 + k] : T(0);
-      tile[k] = v;
+      for (int it = 0; it < SELL_STAGE_IT; ++it) {
+        const int k = kb + tid + it * SELL_THREADS;
+        const int kk = k < kn ? k : klast;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+          const int64_t b = (b0 + q < a.B) ? b0 + q : a.B - 1;
+          stg[it][q] = kn > 0 ? a.R[b * a.ldr + k0 + kk] : T(0);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < SELL_STAGE_IT; ++it) {
+        const int k = kb + tid + it * SELL_THREADS;
+        if (k <= a.KC) {
+          V v;
+#pragma unroll
+          for (int q = 0; q < QT; ++q) v.v[q] = (k < kn && b0 + q < a.B) ? stg[it][q] : T(0);
+          tile[k] = v;
+        }
+      }
     }
     __syncthreads();
 
