@@ -1130,8 +1130,11 @@ __device__ __forceinline__ unsigned float_key(float f) {
 constexpr int TOPL_THREADS = 256;
 constexpr int TOPL_MAX = 1024;
 
+// `only_flagged`: second launch after topl_bound_kernel -- serve only the rows it marked (oidx[row*L] == -1)
 __global__ void __launch_bounds__(TOPL_THREADS) topl_kernel(const float* __restrict__ scores, int64_t ncols, int64_t ld,
-                                                            int L, int* __restrict__ oidx, float* __restrict__ oval) {
+                                                            int L, int* __restrict__ oidx, float* __restrict__ oval,
+                                                            int only_flagged) {
+  if (only_flagged && oidx[(int64_t)blockIdx.x * L] != -1) return;
   __shared__ unsigned hist[256];
   __shared__ unsigned long long sel[TOPL_MAX];  // (key << 32) | ~column : descending sort = score desc, column asc
   __shared__ unsigned s_prefix, s_need, s_count, s_base;
@@ -1220,13 +1223,109 @@ __global__ void __launch_bounds__(TOPL_THREADS) topl_kernel(const float* __restr
   }
 }
 
+// Fast path (two reads of the row instead of six, no per-element histogram): every thread takes the maximum key of its
+// strided share; the L-th largest of those 1024 maxima is a lower bound of the L-th largest element (they are L
+// distinct elements), so only elements at or above it can be among the top L.  They are collected as (key, ~column)
+// pairs -- unique, and their descending order IS score descending / column ascending, so ties need no special case --
+// and bitonic-sorted in LDS.  A row with more than TOPL2_CAP candidates (long runs of equal scores at the bound:
+// e.g. mostly zeros) is marked with oidx = -1 and left to the radix-select kernel above.
+constexpr int TOPL2_THREADS = 1024;
+constexpr int TOPL2_CAP = 4096;
+
+__global__ void __launch_bounds__(TOPL2_THREADS) topl_bound_kernel(const float* __restrict__ scores, int64_t ncols,
+                                                                   int64_t ld, int L, int* __restrict__ oidx,
+                                                                   float* __restrict__ oval) {
+  __shared__ unsigned long long cand[TOPL2_CAP];
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_need, s_count;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float* row = scores + (int64_t)blockIdx.x * ld;
+  unsigned mx = 0;  // smaller than the key of any float
+  for (int64_t c = tid; c < ncols; c += TOPL2_THREADS) {
+    const unsigned k = float_key(row[c]);
+    mx = k > mx ? k : mx;
+  }
+  if (tid == 0) { s_prefix = 0; s_need = (unsigned)L; s_count = 0; }
+  __syncthreads();
+  // radix select of the L-th largest thread maximum (L <= 1024 = number of maxima; threads without elements hold 0)
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    if ((mx & himask) == prefix) atomicAdd(&hist[(mx >> shift) & 255u], 1u);
+    __syncthreads();
+    if (tid == 0) {
+      unsigned need = s_need, b = 255;
+      for (;; --b) {
+        if (hist[b] >= need) break;
+        need -= hist[b];
+        if (b == 0) break;
+      }
+      s_prefix = prefix | (b << shift);
+      s_need = need;
+    }
+    __syncthreads();
+  }
+  const unsigned bound = s_prefix;
+  // candidates: one counter update per wave (ballot), order irrelevant (sorted below)
+  for (int64_t c0 = 0; c0 < ncols; c0 += TOPL2_THREADS) {
+    const int64_t c = c0 + tid;
+    const unsigned k = c < ncols ? float_key(row[c]) : 0u;
+    const bool in = c < ncols && k >= bound;
+    const unsigned long long m = __ballot(in);
+    if (m) {
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&s_count, (unsigned)__popcll(m));
+      base = __shfl(base, 0);
+      const unsigned p = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+      if (in && p < (unsigned)TOPL2_CAP) cand[p] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)c);
+    }
+  }
+  __syncthreads();
+  const unsigned n = s_count;
+  if (n > (unsigned)TOPL2_CAP) {
+    if (tid == 0) oidx[(int64_t)blockIdx.x * L] = -1;
+    return;
+  }
+  int P = 1;
+  while (P < (int)n) P <<= 1;   // n >= L
+  for (int i = (int)n + tid; i < P; i += TOPL2_THREADS) cand[i] = 0ull;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += TOPL2_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = cand[i], b = cand[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) { cand[i] = b; cand[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < L; i += TOPL2_THREADS) {
+    const unsigned long long e = cand[i];
+    const unsigned c = ~(unsigned)(e & 0xFFFFFFFFull);
+    oidx[(int64_t)blockIdx.x * L + i] = (int)c;
+    oval[(int64_t)blockIdx.x * L + i] = row[c];
+  }
+}
+
 int launch_topl(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L, int* oidx, float* oval) {
   if (nrows <= 0) return SS_OK;
   if (L < 1 || L > TOPL_MAX || L > ncols) return fail(SS_EINVAL, "top-L needs 1 <= L <= min(%d, ncols)", TOPL_MAX);
+  const bool fast = !(getenv("SS_TOPL_BOUND") && atoi(getenv("SS_TOPL_BOUND")) == 0);
   for (int64_t r0 = 0; r0 < nrows; r0 += (1 << 30)) {
     const int64_t nb = nrows - r0 < (1 << 30) ? nrows - r0 : (1 << 30);
+    if (fast) {
+      hipLaunchKernelGGL(topl_bound_kernel, dim3((unsigned)nb), dim3(TOPL2_THREADS), 0, ctx().stream, scores + r0 * ld,
+                         ncols, ld, L, oidx + r0 * L, oval + r0 * L);
+      SS_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(topl_kernel, dim3((unsigned)nb), dim3(TOPL_THREADS), 0, ctx().stream, scores + r0 * ld, ncols, ld,
-                       L, oidx + r0 * L, oval + r0 * L);
+                       L, oidx + r0 * L, oval + r0 * L, fast ? 1 : 0);
     SS_LAUNCH_CHECK();
   }
   return SS_OK;

@@ -732,6 +732,27 @@ def test_topl_matches_stable_descending_sort_with_ties():
         np.testing.assert_array_equal(val, np.take_along_axis(x, want, 1))
 
 
+def test_topl_bound_path_and_radix_fallback_agree(monkeypatch):
+    """ss_topl_f32 has a fast path (lower bound from per-thread maxima, candidates sorted) and a radix-select fallback for
+    rows with more than 4096 candidates: distinct scores stay on the fast path, long runs of equal scores at the bound
+    overflow it; both must give the order of a stable descending sort, on rows wider than one pass of the workgroup."""
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((24, 70001)).astype(np.float32)
+    x[1, :] = np.float32(0.0)                          # every element ties: fallback
+    x[2, 5000:] = np.float32(-99.0)                    # cleaned columns below the bound
+    x[3, ::2] = np.float32(3.0)                        # 35001 ties above everything else: fallback (L <= ties)
+    x[4, :90] = np.float32(7.0)                        # ties inside the top L, distinct scores at the bound
+    x[5] = np.round(x[5] * 4) / 4                      # a few dozen distinct values: ties at the bound
+    for L in (1, 100, 1024):
+        idx, val = ss.topl(x, L)
+        want = np.argsort(-x, axis=1, kind="stable")[:, :L]
+        np.testing.assert_array_equal(idx, want)
+        np.testing.assert_array_equal(val, np.take_along_axis(x, want, 1))
+    monkeypatch.setenv("SS_TOPL_BOUND", "0")           # radix select alone
+    idx0, val0 = ss.topl(x, 100)
+    np.testing.assert_array_equal(idx0, np.argsort(-x, axis=1, kind="stable")[:, :100])
+
+
 def test_recall_precision_at_L_reference_kat_and_device_scores(kats):
     k = kats["at_L"]
     for case in k["cases"]:
