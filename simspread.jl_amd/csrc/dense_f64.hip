@@ -44,11 +44,17 @@ struct Dense64Args {
 
 constexpr int D64_BK = 16;
 constexpr int D64_T = 128;        // workgroup tile (rows and columns)
-constexpr int D64_LD = D64_T + 2; // 16-byte aligned LDS rows
+constexpr int D64_LD = D64_T + 2; // 16-byte aligned LDS rows (1040 bytes)
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
-template <bool LOO>
+// WEIGHTED: featurize(..., weighted): the value itself or 1 above the cutoff; GATHER: A rows through row_ids (k-fold).
+// Staging is written for few vector instructions per element -- the first version spent 7.7 VALU instructions per MFMA
+// on bounds checks, 64-bit address arithmetic and selects, and the matrix pipe was busy 46 % of the time
+// (profiles/r02_c4_f64_pmc.txt): everything that does not change along K is computed once per thread (its two A rows
+// and two B rows, their validity folded into the cutoff they are compared with: +inf for a row outside the matrix),
+// loads are unconditional from clamped addresses, and the two adjacent rows of a lane move as one 16-byte access.
+template <bool LOO, bool WEIGHTED, bool GATHER>
 __global__ void __launch_bounds__(256) transfer_dense_f64_kernel(Dense64Args a) {
   __shared__ __align__(16) double As[2][D64_BK][D64_LD];
   __shared__ __align__(16) double Bs[2][D64_BK][D64_LD];
@@ -74,43 +80,70 @@ __global__ void __launch_bounds__(256) transfer_dense_f64_kernel(Dense64Args a) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 
-  // staging: thread t takes elements (kk, mp .. mp+1) with kk = e / 64, mp = (e % 64) * 2 for e = t, t + 256, ...
-  constexpr int IT = D64_BK * D64_T / 2 / 256;  // 4 pairs per thread, operand and K-step
-  double ra[IT][2], rb[IT][2], rw[IT];
-  // A rows: contiguous (row_begin + m) or gathered (row_ids)
+  // staging: thread t owns tile rows mp, mp + 1 (mp = 2 * lane) of both operands and the k values wave + 4 * it of a step
+  constexpr int IT = D64_BK / 4;
+  const int mp = lane * 2;
   auto arow = [&](int64_t m) __attribute__((always_inline)) {
-    return a.row_ids ? (int64_t)a.row_ids[a.row_begin + m] : a.row_begin + m;
+    return GATHER ? (int64_t)a.row_ids[a.row_begin + m] : a.row_begin + m;
   };
+  const double inf = __builtin_huge_val();
+  int64_t rowa[2];        // A row (clamped) of tile rows mp, mp + 1
+  double cuta[2], cutb[2];  // the cutoff they are compared with: +inf outside the matrix -> staged as 0
+  const double* pb;       // B rows are contiguous: n0 + mp (+1)
+  {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int64_t m = m0 + mp + x;
+      rowa[x] = arow(m < a.M ? m : a.M - 1);
+      cuta[x] = m < a.M ? a.alpha : inf;
+      cutb[x] = (n0 + mp + x < a.N) ? a.alpha : inf;
+    }
+  }
+  // two adjacent rows in one 16-byte access when they are adjacent in memory and inside the matrix (else two 8-byte ones)
+  // (both conditions are the same for every lane of the workgroup: scalar branches)
+  const bool pair_a = !GATHER && (m0 + D64_T <= a.M) && (((a.row_begin + m0) & 1) == 0) && ((a.lda & 1) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+  const bool pair_b = (n0 + D64_T <= a.N) && ((a.ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+  const int64_t nb0 = (n0 + mp < a.N) ? n0 + mp : a.N - 1, nb1 = (n0 + mp + 1 < a.N) ? n0 + mp + 1 : a.N - 1;
+  pb = a.B;
+  using d2 = __attribute__((ext_vector_type(2))) double;
+  double ra[IT][2], rb[IT][2], rw[IT];
   auto load_raw = [&](int64_t k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int e = tid + it * 256;
-      const int kk = e >> 6, mp = (e & 63) * 2;
-      const int64_t k = k0 + kk;
-      ra[it][0] = ra[it][1] = rb[it][0] = rb[it][1] = 0.0;
-      rw[it] = 0.0;
-      if (k < a.K) {
-        rw[it] = a.inv_k[k];
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          if (m0 + mp + x < a.M) ra[it][x] = a.A[arow(m0 + mp + x) + k * a.lda];
-          if (n0 + mp + x < a.N) rb[it][x] = a.B[n0 + mp + x + k * a.ldb];
-        }
+      const int64_t k = k0 + wave + 4 * it;            // wave-uniform
+      const int64_t kc = k < a.K ? k : a.K - 1;        // clamped: a step past K reads valid data and weighs it with 0
+      rw[it] = k < a.K ? a.inv_k[kc] : 0.0;
+      if (pair_a) {
+        const d2 v = *reinterpret_cast<const d2*>(a.A + rowa[0] + kc * a.lda);
+        ra[it][0] = v[0]; ra[it][1] = v[1];
+      } else {
+        ra[it][0] = a.A[rowa[0] + kc * a.lda];
+        ra[it][1] = a.A[rowa[1] + kc * a.lda];
+      }
+      if (pair_b) {
+        const d2 v = *reinterpret_cast<const d2*>(pb + nb0 + kc * a.ldb);
+        rb[it][0] = v[0]; rb[it][1] = v[1];
+      } else {
+        rb[it][0] = pb[nb0 + kc * a.ldb];
+        rb[it][1] = pb[nb1 + kc * a.ldb];
       }
     }
   };
   auto store_tiles = [&](int64_t k0, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int e = tid + it * 256;
-      const int kk = e >> 6, mp = (e & 63) * 2;
+      const int kk = wave + 4 * it;
+      d2 va, vb;
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
-        double va = (m0 + mp + x < a.M) ? cut64(ra[it][x], a.alpha, a.weighted) * rw[it] : 0.0;
-        if (LOO && (k0 + kk) == arow(m0 + mp + x < a.M ? m0 + mp + x : 0)) va = 0.0;  // the query's own feature is not in the fold
-        As[buf][kk][mp + x] = va;
-        Bs[buf][kk][mp + x] = (n0 + mp + x < a.N) ? cut64(rb[it][x], a.alpha, a.weighted) : 0.0;
+        bool on = ra[it][x] >= cuta[x];
+        if (LOO) on = on && (k0 + kk != rowa[x]);   // the query's own feature is not in the fold
+        va[x] = on ? (WEIGHTED ? ra[it][x] * rw[it] : rw[it]) : 0.0;
+        vb[x] = (rb[it][x] >= cutb[x]) ? (WEIGHTED ? rb[it][x] : 1.0) : 0.0;
       }
+      *reinterpret_cast<d2*>(&As[buf][kk][mp]) = va;
+      *reinterpret_cast<d2*>(&Bs[buf][kk][mp]) = vb;
     }
   };
 
@@ -192,8 +225,16 @@ int launch_transfer_dense_f64(const DenseSim<double>& d, bool loo, const double*
   a.gx = (int)ceil_div(d.ns, D64_T);
   a.gy = (int)ceil_div(nrows, D64_T);
   dim3 grid((unsigned)(a.gx * a.gy));
-  if (loo) hipLaunchKernelGGL(transfer_dense_f64_kernel<true>, grid, dim3(256), 0, ctx().stream, a);
-  else hipLaunchKernelGGL(transfer_dense_f64_kernel<false>, grid, dim3(256), 0, ctx().stream, a);
+  const bool gather = row_ids != nullptr;
+#define SS_D64(L, W, G) hipLaunchKernelGGL((transfer_dense_f64_kernel<L, W, G>), grid, dim3(256), 0, ctx().stream, a)
+  if (loo) {
+    if (d.weighted) SS_D64(true, true, false); else SS_D64(true, false, false);
+  } else if (gather) {
+    if (d.weighted) SS_D64(false, true, true); else SS_D64(false, false, true);
+  } else {
+    if (d.weighted) SS_D64(false, true, false); else SS_D64(false, false, false);
+  }
+#undef SS_D64
   SS_LAUNCH_CHECK();
   return SS_OK;
 }

@@ -49,7 +49,7 @@ def main():
         from oracle import simspread_oracle as O
         import scipy.sparse as sp
         Sh = S.cpu().numpy()
-        X = O.cutoff(Sh.astype(np.float64), float(np.float32(alphas[-1])), False)
+        X = O.cutoff(Sh.astype(np.float64), float(alphas[-1]) if f64 else float(np.float32(alphas[-1])), False)   # the cutoff in the graph's precision
         Y = sp.csr_matrix((np.ones(yi.numel()), yi.cpu().numpy(), yp.cpu().numpy()), shape=(n, nt))
         qs = [0, folds // 2, folds - 1]
         want = O.predict_loo_dense(X, Y, clean_flag=True, queries=qs)
