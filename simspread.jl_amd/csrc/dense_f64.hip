@@ -130,31 +130,34 @@ __global__ void __launch_bounds__(256) transfer_dense_f64_kernel(Dense64Args a) 
       }
     }
   };
-  auto store_tiles = [&](int64_t k0, int buf) __attribute__((always_inline)) {
+  // one quarter of the staging work of a K-step (the k value wave + 4 * it of both operands)
+  auto store_piece = [&](int64_t k0, int buf, int it) __attribute__((always_inline)) {
+    const int kk = wave + 4 * it;
+    d2 va, vb;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int kk = wave + 4 * it;
-      d2 va, vb;
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        bool on = ra[it][x] >= cuta[x];
-        if (LOO) on = on && (k0 + kk != rowa[x]);   // the query's own feature is not in the fold
-        va[x] = on ? (WEIGHTED ? ra[it][x] * rw[it] : rw[it]) : 0.0;
-        vb[x] = (rb[it][x] >= cutb[x]) ? (WEIGHTED ? rb[it][x] : 1.0) : 0.0;
-      }
-      *reinterpret_cast<d2*>(&As[buf][kk][mp]) = va;
-      *reinterpret_cast<d2*>(&Bs[buf][kk][mp]) = vb;
+    for (int x = 0; x < 2; ++x) {
+      bool on = ra[it][x] >= cuta[x];
+      if (LOO) on = on && (k0 + kk != rowa[x]);   // the query's own feature is not in the fold
+      va[x] = on ? (WEIGHTED ? ra[it][x] * rw[it] : rw[it]) : 0.0;
+      vb[x] = (rb[it][x] >= cutb[x]) ? (WEIGHTED ? rb[it][x] : 1.0) : 0.0;
     }
+    *reinterpret_cast<d2*>(&As[buf][kk][mp]) = va;
+    *reinterpret_cast<d2*>(&Bs[buf][kk][mp]) = vb;
   };
 
   load_raw(0);
-  store_tiles(0, 0);
+#pragma unroll
+  for (int it = 0; it < IT; ++it) store_piece(0, 0, it);
   __syncthreads();
-  if (D64_BK < a.K) load_raw(D64_BK);
+  load_raw(D64_BK);   // (clamped past K: valid addresses, weight 0)
   int cur = 0;
   for (int64_t k0 = 0; k0 < a.K; k0 += D64_BK) {
+    // The tile of the next K-step is thresholded and parked in the other LDS buffer piece by piece BETWEEN the four MFMA
+    // groups of this step (same basic block, no branches: a step past K stages zero weights into a buffer nobody reads),
+    // so the vector and LDS-store instructions issue while the matrix pipe works instead of after it.
 #pragma unroll
-    for (int kk = 0; kk < D64_BK; kk += 4) {
+    for (int st = 0; st < D64_BK / 4; ++st) {
+      const int kk = 4 * st;
       // A operand of v_mfma_f64_16x16x4_f64: lane l holds A[l % 16][l / 16]; B operand: B[l / 16][l % 16]
       const int kr = kk + (lane >> 4);
       const int c = lane & 15;
@@ -167,10 +170,10 @@ __global__ void __launch_bounds__(256) transfer_dense_f64_kernel(Dense64Args a) 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+      store_piece(k0 + D64_BK, cur ^ 1, st);
     }
-    if (k0 + D64_BK < a.K) store_tiles(k0 + D64_BK, cur ^ 1);
     __syncthreads();
-    if (k0 + 2 * D64_BK < a.K) load_raw(k0 + 2 * D64_BK);  // in flight during the next MFMA loop
+    load_raw(k0 + 2 * D64_BK);  // in flight during the next MFMA loop
     cur ^= 1;
   }
   // C/D layout of v_mfma_f64_16x16x4_f64 (probed on MI355X with one-hot operands): col = lane % 16,
