@@ -64,6 +64,28 @@ __global__ void __launch_bounds__(64) variant_b(const unsigned short* __restrict
   if (acc == 12345.678f) out[0] = acc;
 }
 
+// C: the same sub-rows stored as ONE contiguous block each (128 B of indices directly followed by 256 B of values):
+// one run of 384 bytes instead of two runs in two arrays -- fewer 64-byte sectors per sub-row
+__global__ void __launch_bounds__(64) variant_c(const unsigned char* __restrict__ blk, const int* __restrict__ starts,
+                                                float* out) {
+  const int lane = threadIdx.x;
+  const int* st = starts + (size_t)blockIdx.x * PER_WAVE;
+  float acc = 0.f;
+  for (int i = 0; i < PER_WAVE; i += 8) {
+    unsigned short j[8]; float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = __builtin_amdgcn_readfirstlane(st[i + u]);       // block start in units of 6 bytes * 8 = 48 B steps
+      const unsigned char* p = blk + (size_t)b * 6;
+      j[u] = reinterpret_cast<const unsigned short*>(p)[lane];
+      v[u] = reinterpret_cast<const float*>(p + 128)[lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u] * (float)j[u];
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
 int main() {
   const size_t table = 640000;   // entries: 1.28 MB idx + 2.56 MB val = one XCD's chunk at C2
   unsigned short* idx; float* val; int* starts; float* out;
@@ -76,17 +98,19 @@ int main() {
   for (auto& x : h) x = (rand() % (int)(table / 8 - 8)) * 8;   // 16-byte aligned for both arrays
   CK(hipMemcpy(starts, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int var = 0; var < 2; ++var) {
+  unsigned char* blk; CK(hipMalloc(&blk, (table + 128) * 6 + 512)); CK(hipMemset(blk, 0, (table + 128) * 6 + 512));
+  for (int var = 0; var < 3; ++var) {
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipEventRecord(a));
       if (var == 0) hipLaunchKernelGGL(variant_a, dim3(waves), dim3(64), 0, 0, idx, val, starts, out);
-      else hipLaunchKernelGGL(variant_b, dim3(waves), dim3(64), 0, 0, idx, val, starts, out);
+      else if (var == 1) hipLaunchKernelGGL(variant_b, dim3(waves), dim3(64), 0, 0, idx, val, starts, out);
+      else hipLaunchKernelGGL(variant_c, dim3(waves), dim3(64), 0, 0, blk, starts, out);
       CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
     }
     const double subrows = (double)waves * PER_WAVE;
     printf("%s: %.3f ms  %.1f G sub-rows/s  %.2f TB/s  (%.1f clk per sub-row per CU at 2.4 GHz)\n",
-           var == 0 ? "A narrow register loads" : "B LDS-DMA 16-byte pieces", ms, subrows / ms / 1e6,
+           var == 0 ? "A narrow register loads" : (var == 1 ? "B LDS-DMA 16-byte pieces" : "C one 384-byte block per sub-row"), ms, subrows / ms / 1e6,
            subrows * 384 / ms / 1e9, ms * 1e-3 * 2.4e9 * 256 / subrows);
   }
   return 0;
