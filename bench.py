@@ -145,40 +145,95 @@ def build_c3(ss, torch):
     return g, n
 
 
-def c3_loo_curve(args, ss, torch, dist, world, rank, backend):
+def make_agree(torch, dist, world, backend):
+    """agree(ok) -> True only if every rank says ok (one tiny MIN all-reduce).  Called after the rank-local part of a leg
+    and before its exchange, so that a rank that failed locally does not let its peers walk into a collective alone."""
+    def agree(ok=True):
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+    return agree
+
+
+def lib_comm_start(ss, dist, world, rank):
+    """The library's own RCCL communicator (ss_comm_*; what a Julia caller uses): rank 0's unique id travels over
+    torch.distributed's store, every rank joins."""
+    ids = [ss.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ss.comm_init(ids[0], rank, world)
+
+
+def lib_gather_check(ss, torch, out, world, rank):
+    """Before anything is timed: the in-library gather (ss_gather_rows_f32, grouped ncclSend/ncclRecv on the library's
+    communicator) against the torch.distributed exchange, bit for bit, on a small block with UNEVEN row counts -- all
+    ranks receiving, and rank (world-1) only."""
+    counts = [3 + 2 * r for r in range(world)]
+    blk = out[:counts[rank]].contiguous()
+    tot = sum(counts)
+    a = ss.gather_scores(blk, tot, counts=counts)
+    b = ss.lib_gather_scores(blk, counts)
+    same_all = bool(torch.equal(a, b))
+    root = world - 1
+    ar = ss.gather_scores(blk, tot, root=root, counts=counts)
+    br = ss.lib_gather_scores(blk, counts, root=root)
+    same_root = (ar is None and br is None) if rank != root else bool(torch.equal(ar, br))
+    return same_all and same_root, counts
+
+
+def c3_loo_curve(args, ss, torch, dist, world, rank, backend, agree=None, state=None):
     """BASELINE configs[2] on this run's ranks: 100k x 100k, 1 %, leave-one-out; the 10^5 folds are block-sharded
     (ss.shard_range), every rank scores `--folds` consecutive folds of its shard per step (same per-rank work at every
     N: weak scaling in the step, i.e. the full 10^5-fold job gets N times faster).  Reported without any exchange, with
-    the direct all-to-all gather of the score blocks, with a gather to rank 0 only, and with the reduced gather of the
-    top-L predictions per fold."""
-    g, n = build_c3(ss, torch)
-    lo, hi = ss.shard_range(n, rank, world)
-    folds = min(args.folds, hi - lo)
-    out = torch.empty((folds, n), dtype=torch.float32, device="cuda")
+    the direct all-to-all gather of the score blocks (torch.distributed AND, on RCCL, the library's own communicator),
+    with a gather to rank 0 only, and with the reduced gather of the top-L predictions per fold."""
+    agree = agree or make_agree(torch, dist, world, backend)
+    state = state if state is not None else {}
     steps = args.c3_steps
+    try:
+        g, n = build_c3(ss, torch)
+        lo, hi = ss.shard_range(n, rank, world)
+        folds = min(args.folds, hi - lo)
+        out = torch.empty((folds, n), dtype=torch.float32, device="cuda")
+        g.predict_loo(lo, lo + folds, clean=True, out=out)   # warm (operands are cut at first use)
+        torch.cuda.synchronize()
+        ok = True
+    except Exception as e:   # rank-local set-up failed: say so everywhere before anybody enters an exchange
+        ok, err = False, repr(e)
+    if not agree(ok):
+        return {"error": "set-up failed on a rank (%s)" % (err if not ok else "another rank")}
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(exchange):
-        pos = lo
-        g.predict_loo(pos, pos + folds, clean=True, out=out)   # warm (operands are cut at first use)
-        if exchange:
-            exchange()
-        barrier()
-        ss.timing_hold(True)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            b = lo + (i * folds) % max(1, (hi - lo) - folds + 1)
-            g.predict_loo(b, b + folds, clean=True, out=out)
+    def run(name, exchange):
+        """One timed leg; returns (seconds, stage timings) or None when a rank failed (agreed on by all ranks)."""
+        state["leg"] = "c3_loo:" + name
+        el = t = None
+        try:
             if exchange:
                 exchange()
-        barrier()
-        el = time.perf_counter() - t0
-        t = ss.timing_last()
-        ss.timing_hold(False)
+            barrier()
+            ss.timing_hold(True)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                b = lo + (i * folds) % max(1, (hi - lo) - folds + 1)
+                g.predict_loo(b, b + folds, clean=True, out=out)
+                if exchange:
+                    exchange()
+            barrier()
+            el = time.perf_counter() - t0
+            t = ss.timing_last()
+            ss.timing_hold(False)
+            good = True
+        except Exception as e:
+            good = False
+            state.setdefault("errors", []).append("%s on rank %d: %r" % (name, rank, e))
+        if not agree(good):
+            return None
         if world > 1:
             te = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -201,7 +256,10 @@ def c3_loo_curve(args, ss, torch, dist, world, rank, backend):
             ti, tv = ti.cpu(), tv.cpu()
         ss.gather_topl(ti, tv, folds * world, counts=counts)
 
-    el0, t = run(None)
+    r0 = run("no_exchange", None)
+    if r0 is None:
+        return {"error": "the leg without exchange failed", "errors": state.get("errors")}
+    el0, t = r0
     res = {"workload": "BASELINE configs[2]: 100k x 100k, 1%% density, leave-one-out, folds block-sharded over ranks; %d folds "
                        "per rank and step, %d steps" % (folds, steps),
            "nnz_X": g.nnz_xs, "nnz_Y": g.nnz_ys, "folds_per_rank_step": folds,
@@ -209,27 +267,150 @@ def c3_loo_curve(args, ss, torch, dist, world, rank, backend):
            "ms_per_step": el0 / steps * 1e3,
            "stage1_ms": t["transfer_ms"] / max(1, t["transfer_launches"]), "stage2_ms": t["spmm_ms"] / max(1, t["spmm_launches"]),
            "full_loo_seconds_at_this_rate": n / (folds * world * steps / el0)}
+
+    def put(key, r, extra=None):
+        if r is None:
+            res[key] = {"error": "a rank failed in this leg", "errors": state.get("errors")}
+            return False
+        res[key] = {"folds_per_s": folds * world * steps / r[0], "ms_per_step": r[0] / steps * 1e3}
+        res[key].update(extra or {})
+        return True
+
+    alive = True
     if world > 1:
-        el1, _ = run(ex_all)
-        el2, _ = run(ex_root)
-        res["with_gather_all_ranks"] = {"folds_per_s": folds * world * steps / el1, "ms_per_step": el1 / steps * 1e3,
-                                        "bytes_received_per_rank_step": folds * (world - 1) * n * 4,
-                                        "how": "direct point-to-point exchange of exact row blocks (grouped ncclSend/ncclRecv)"}
-        res["with_gather_to_rank0"] = {"folds_per_s": folds * world * steps / el2, "ms_per_step": el2 / steps * 1e3}
-    if world > 1 and backend == "nccl" and os.environ.get("BENCH_LIB_GATHER") == "1":
-        # opt-in: the same exchange through the library's own RCCL communicator (ss_comm_init / ss_gather_rows_f32) instead
-        # of torch.distributed -- what a Julia caller would use.  Off by default: its peer-to-peer legs cannot be exercised
-        # on the one-GPU boxes this repository is developed on.
-        ids = [ss.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ss.comm_init(ids[0], rank, world)
-        el4, _ = run(lambda: ss.lib_gather_scores(out, counts))
-        ss.comm_destroy()
-        res["with_gather_all_ranks_in_library_rccl"] = {"folds_per_s": folds * world * steps / el4, "ms_per_step": el4 / steps * 1e3}
-    el3, _ = run(ex_topl if world > 1 else (lambda: ss.topl(out, 100)))
-    res["with_topL_reduction_L100"] = {"folds_per_s": folds * world * steps / el3, "ms_per_step": el3 / steps * 1e3,
-                                       "bytes_received_per_rank_step": folds * (world - 1) * 100 * 8,
-                                       "how": "ss_topl_f32 on the device, then the same exchange on 100 (column, score) pairs per fold"}
+        alive = put("with_gather_all_ranks", run("gather_all_ranks", ex_all),
+                    {"bytes_received_per_rank_step": folds * (world - 1) * n * 4,
+                     "how": "direct point-to-point exchange of exact row blocks (torch.distributed batch_isend_irecv: grouped "
+                            "ncclSend/ncclRecv on RCCL)"})
+        alive = alive and put("with_gather_to_rank0", run("gather_to_rank0", ex_root))
+    if alive and world > 1 and backend == "nccl" and os.environ.get("BENCH_LIB_GATHER", "1") != "0":
+        # the same exchange through the library's own RCCL communicator (ss_comm_init / ss_gather_rows_f32) -- what a
+        # Julia caller uses; on by default, checked bit for bit against the torch exchange before it is timed
+        state["leg"] = "c3_loo:library_rccl_gather_check"
+        try:
+            lib_comm_start(ss, dist, world, rank)
+            same, small = lib_gather_check(ss, torch, out, world, rank)
+            good = True
+        except Exception as e:
+            good, same, small = False, False, None
+            state.setdefault("errors", []).append("library gather on rank %d: %r" % (rank, e))
+        if agree(good):
+            same = agree(same)
+            ok4 = put("with_gather_all_ranks_in_library_rccl", run("gather_all_ranks_library", lambda: ss.lib_gather_scores(out, counts)),
+                      {"bitwise_equal_to_torch_exchange": same, "checked_on_row_counts": small,
+                       "how": "ss_gather_rows_f32: one ncclRecv per peer into its slice + one ncclSend per peer inside one "
+                              "ncclGroupStart/End on the library's communicator (comm.hip)"})
+            alive = alive and ok4
+            try:
+                ss.comm_destroy()
+            except Exception:
+                pass
+        else:
+            res["with_gather_all_ranks_in_library_rccl"] = {"error": "communicator set-up or check failed", "errors": state.get("errors")}
+            alive = False
+    if alive:
+        put("with_topL_reduction_L100", run("topL", ex_topl if world > 1 else (lambda: ss.topl(out, 100))),
+            {"bytes_received_per_rank_step": folds * (world - 1) * 100 * 8,
+             "how": "ss_topl_f32 on the device, then the same exchange on 100 (column, score) pairs per fold"})
+    g.close()
+    return res
+
+
+def build_c5(ss, torch, n=100_000):
+    """BASELINE configs[4] at its specified weight: 10^5 sources + 10^5 targets, source degrees and target
+    popularity Zipf(1.2) with mean 1000 after de-duplication (tools/c5_powerlaw.py), X as C3.  Same bytes on every rank."""
+    from tools.c3_loo import rand_sym_csr
+    from tools.c5_powerlaw import zipf_bipartite_spec
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20250222 + 5)
+    xp, xi = rand_sym_csr(n, 0.01, gen)
+    yp, yi = zipf_bipartite_spec(n, n, 1000.0, 1.2, gen)
+    xv = (0.5 + 0.5 * torch.rand(xi.numel(), device="cuda", generator=gen)).float()
+    g = ss.DeviceGraph.from_device_csr(0, n, n, n, None, (xp, xi, xv), (yp, yi, None), dtype=np.float32)
+    # work of fold i: stage 1 walks the feature columns of row i of X (sum of their lengths); stage 2 is the same for
+    # every fold (one column of R against all of W = Y')
+    collen = torch.bincount(xi.long(), minlength=n).double()
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (xp[1:] - xp[:-1]))
+    w1 = torch.zeros(n, dtype=torch.float64, device="cuda").index_add_(0, rows, collen[xi.long()])
+    ymax_row = int((yp[1:] - yp[:-1]).max().item())
+    ymax_col = int(torch.bincount(yi.long(), minlength=n).max().item())
+    return g, n, w1.cpu().numpy(), int(yi.numel()), ymax_row, ymax_col
+
+
+def c5_loo_leg(args, ss, torch, dist, world, rank, backend, agree=None, state=None):
+    """BASELINE configs[4] (power-law, 200k nodes): the leave-one-out folds of the whole graph are sharded over this run's
+    ranks by ss.shard_range(weights=per-fold work) -- the nnz-balanced partition of SURVEY.md 8(e) -- and, for
+    comparison, by equal fold counts.  Every rank scores ITS WHOLE SHARD (strong scaling: the job is the full LOO, capped
+    by --c5-folds), `--folds` folds per launch; wall = slowest rank.  No exchange: scores are reduced where they are made."""
+    agree = agree or make_agree(torch, dist, world, backend)
+    state = state if state is not None else {}
+    state["leg"] = "c5_loo:set-up"
+    try:
+        g, n, w1, nnz_y, ymax_row, ymax_col = build_c5(ss, torch)
+        total = min(n, args.c5_folds)
+        # per-fold weight: the stage-1 work of the fold plus the (fold-independent) stage-2 work, both in multiply-adds
+        w = (w1 + float(nnz_y))[:total]
+        out = torch.empty((args.folds, n), dtype=torch.float32, device="cuda")
+        g.predict_loo(0, min(args.folds, total), clean=True, out=out[:min(args.folds, total)])   # warm: operands are cut at first use
+        torch.cuda.synchronize()
+        ok = True
+    except Exception as e:
+        ok = False
+        state.setdefault("errors", []).append("c5 set-up on rank %d: %r" % (rank, e))
+    if not agree(ok):
+        return {"error": "set-up failed on a rank", "errors": state.get("errors")}
+
+    def timed(lo, hi):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in range(lo, hi, args.folds):
+            e = min(hi, b + args.folds)
+            g.predict_loo(b, e, clean=True, out=out[:e - b])
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        per_rank = [mine]
+        if world > 1:
+            dev = "cuda" if backend == "nccl" else "cpu"
+            tt = torch.zeros(world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(tt, torch.tensor([mine], dtype=torch.float64, device=dev))
+            per_rank = [float(x) for x in tt.tolist()]
+            tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            wall = float(tw.item())
+        return wall, per_rank
+
+    res = {"workload": "BASELINE configs[4]: 1e5 sources + 1e5 targets, Zipf(1.2) source degrees and target popularity, "
+                       "nnz(Y) = %d (hottest source in %d targets, hottest target in %d sources), X as configs[2]; "
+                       "leave-one-out over the first %d folds, sharded over %d rank(s), %d folds per launch"
+                       % (nnz_y, ymax_row, ymax_col, total, world, args.folds),
+           "folds_total": total}
+    for name, wts in (("nnz_balanced_shards", w), ("equal_count_shards", None)):
+        if name == "equal_count_shards" and world == 1:
+            break   # one rank: both partitions are the whole range
+        state["leg"] = "c5_loo:" + name
+        lo, hi = ss.shard_range(total, rank, world, weights=wts)
+        try:
+            wall, per_rank = timed(lo, hi)
+            good = True
+        except Exception as e:
+            good = False
+            state.setdefault("errors", []).append("%s on rank %d: %r" % (name, rank, e))
+        if not agree(good):
+            res[name] = {"error": "a rank failed", "errors": state.get("errors")}
+            break
+        blocks = [ss.shard_range(total, r, world, weights=wts) for r in range(world)]
+        loads = [float(w[a:b].sum()) for a, b in blocks]
+        res[name] = {"wall_s": wall, "folds_per_s": total / wall, "edges_per_s": total * n / wall,
+                     "folds_per_rank": [b - a for a, b in blocks], "seconds_per_rank": per_rank,
+                     "work_imbalance_max_over_mean": max(loads) / (sum(loads) / world)}
+    res["note"] = ("per-fold work at this config is nearly uniform (X is uniform; the power law sits in Y = the stage-2 operand, "
+                   "which every fold multiplies in full and whose hot rows are split inside the kernel), so the two partitions "
+                   "differ by a few folds; the weighted partition is what a skewed X needs")
     g.close()
     return res
 
@@ -299,6 +480,22 @@ def literal_dense_baseline(ss, n_small, dx, dy):
             "wall_s": dt, "gflops": 4.0 * N ** 3 / dt / 1e9, "max_rel_err_gpu_vs_cpu": err}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child and hand back its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,11 +514,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the configs[2] leave-one-out curve")
+    ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (power-law) nnz-balanced leave-one-out leg")
+    ap.add_argument("--c5-folds", type=int, default=100_000, help="configs[4]: folds of the job that is sharded over the ranks")
     ap.add_argument("--dense-n", type=int, default=3000, help="literal dense CPU baseline: nodes per layer (N = 4x this)")
     ap.add_argument("--aux-timeout", type=int, default=300,
                     help="N > 1: seconds the auxiliary legs (configs[2] curve) may take before the headline line is printed without them")
     ap.add_argument("--gather", action="store_true", help="also time the final gather of the C2 score blocks (outside `value`)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, all-reduce one number over gloo on the CPU, print it and exit (tests the launch path without a GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU
+        # yet (no torch import, no HIP call), and the ranks are fresh child processes of torch.distributed.run -- never
+        # an exec of a process that initialised the device.  Rank 0's JSON line goes to our stdout unchanged.
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -329,6 +536,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rendezvous_only:
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rendezvous": {"world": world, "sum_of_rank_plus_1": int(t.item()), "gpus_arg": args.gpus}}), flush=True)
+        return
     backend = os.environ.get("BENCH_BACKEND", "nccl")  # "gloo" + BENCH_SINGLE_DEVICE=1: rehearsal on a 1-GPU box
     if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
@@ -338,9 +555,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    elif args.gpus > 1:
-        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
     torch.cuda.set_device(local_rank)
 
     import simspread_jl_amd as ss
@@ -393,21 +607,30 @@ def main():
         barrier()
         gather_ms = (time.perf_counter() - tg) * 1e3
 
+    import threading
     result = None
-    state = {"printed": False}
+    state = {"printed": False, "leg": "headline"}
+    emit_lock = threading.Lock()
 
     def emit(extra=None):
-        # the ONE JSON line of the contract (rank 0), whatever happens to the auxiliary legs
-        if rank == 0 and result is not None and not state["printed"]:
-            state["printed"] = True
-            if extra:
-                result.update(extra)
-            print(json.dumps(result), flush=True)
+        # the ONE JSON line of the contract (rank 0), whatever happens to the auxiliary legs; the watchdog thread and the
+        # main thread may both get here: first one prints, under the lock
+        with emit_lock:
+            if rank == 0 and result is not None and not state["printed"]:
+                state["printed"] = True
+                if extra:
+                    result.update(extra)
+                print(json.dumps(result), flush=True)
 
     def watchdog():
-        # an auxiliary leg did not come back (a peer died inside an exchange, a hung collective): keep the headline
-        emit({"c3_loo": {"error": "auxiliary leg exceeded %d s; dropped" % args.aux_timeout}})
-        os._exit(0)
+        # an auxiliary leg did not come back (a peer died inside an exchange, a hung collective): keep the headline, say
+        # which leg hung, and make the hang visible in the exit code (never a silent rc 0)
+        if rank != 0:
+            time.sleep(5.0)   # let rank 0 print before the launcher tears the job down on the first non-zero exit
+        emit({"aux_hang": {"leg": state["leg"], "timeout_s": args.aux_timeout, "errors": state.get("errors")}})
+        sys.stderr.write("bench.py rank %d: auxiliary leg %r exceeded %d s; exiting 3\n" % (rank, state["leg"], args.aux_timeout))
+        sys.stderr.flush()
+        os._exit(3)
 
     if rank == 0:
         nnz_w = g.nnz_ys
@@ -474,17 +697,23 @@ def main():
     # ---- auxiliary legs, after the headline numbers are final and under a watchdog (never lose the headline line)
     timer = None
     if world > 1:
-        import threading
         timer = threading.Timer(args.aux_timeout, watchdog)
         timer.daemon = True
         timer.start()
+    agree = make_agree(torch, dist, world, backend)
     if not args.no_c3:
-        try:
-            c3 = c3_loo_curve(args, ss, torch, dist, world, rank, backend)
-        except Exception as e:
-            c3 = {"error": repr(e)}
+        c3 = c3_loo_curve(args, ss, torch, dist, world, rank, backend, agree, state)
         if rank == 0:
-            result["c3_loo"] = c3
+            with emit_lock:
+                result["c3_loo"] = c3
+    if not args.no_c5:
+        c5 = c5_loo_leg(args, ss, torch, dist, world, rank, backend, agree, state)
+        if rank == 0:
+            with emit_lock:
+                result["c5_loo"] = c5
+    state["leg"] = "done"
+    if timer is not None:
+        timer.cancel()   # the exchanges are over: what follows is rank-local (sweep, CPU baselines) and not under the timeout
 
     if rank == 0:
         if not args.no_sweep and world == 1:
@@ -533,8 +762,6 @@ def main():
             dist.destroy_process_group()
         except Exception:
             pass
-    if timer is not None:
-        timer.cancel()
 
 
 if __name__ == "__main__":

@@ -37,6 +37,33 @@ int require_init() {
   return SS_OK;
 }
 
+// registry of the per-thread Timing objects (their hipEvent pools): ss_shutdown destroys every thread's events, not
+// only the calling thread's; a thread that exits destroys its own.  The mutex orders the two.
+static std::mutex& timing_reg_mu() {
+  static std::mutex m;
+  return m;
+}
+static std::vector<Timing*>& timing_reg() {
+  static std::vector<Timing*> v;
+  return v;
+}
+Timing::Timing() {
+  std::lock_guard<std::mutex> lk(timing_reg_mu());
+  timing_reg().push_back(this);
+}
+Timing::~Timing() {
+  std::lock_guard<std::mutex> lk(timing_reg_mu());
+  auto& v = timing_reg();
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == this) {
+      v[i] = v.back();
+      v.pop_back();
+      break;
+    }
+  if (ctx().inited && generation == ctx().generation)
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+}
+
 Timing& timing() {
   static thread_local Timing t;
   if (t.generation != ctx().generation) {  // the context these events belonged to is gone
@@ -961,13 +988,18 @@ static int shutdown_locked() {
   Ctx& c = ctx();
   if (!c.inited) return SS_OK;
   (void)hipStreamSynchronize(c.stream);
-  Timing& t = timing();
-  for (hipEvent_t e : t.pool) (void)hipEventDestroy(e);
-  t.pool.clear();
-  t.spans.clear();
-  t.used = 0;
-  ++c.generation;  // other threads drop their (now stale) event lists at their next call
-  t.generation = c.generation;
+  {
+    // the exclusive context lock is held: no other thread is inside an entry point, so every thread's pool is quiescent
+    std::lock_guard<std::mutex> lk(timing_reg_mu());
+    for (Timing* t : timing_reg()) {
+      if (t->generation == c.generation)
+        for (hipEvent_t e : t->pool) (void)hipEventDestroy(e);
+      t->pool.clear();
+      t->spans.clear();
+      t->used = 0;
+    }
+  }
+  ++c.generation;  // other threads notice at their next call (their lists are already empty)
   (void)hipStreamDestroy(c.own_stream);
   c.own_stream = nullptr;
   c.stream = nullptr;

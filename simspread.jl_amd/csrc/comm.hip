@@ -145,16 +145,26 @@ int gather_rows(const void* local, int64_t ncols, const int64_t* counts, void* f
     SS_HIP(hipMemcpyAsync(static_cast<char*>(full) + mine * ncols * elem, local, (size_t)counts[r.rank] * ncols * elem,
                           hipMemcpyDeviceToDevice, st));
   SS_NCCL(r.GroupStart());
-  for (int p = 0; p < r.nranks; ++p) {
+  // inside the group no early return: a failed Send/Recv must still reach GroupEnd, or the group stays open and every
+  // later RCCL call of this process nests in it and never launches
+  int bad = NCCL_SUCCESS;
+  const char* what = "";
+  for (int p = 0; p < r.nranks && bad == NCCL_SUCCESS; ++p) {
     if (p != r.rank) {
-      if (receives && counts[p] > 0)
-        SS_NCCL(r.Recv(static_cast<char*>(full) + start * ncols * elem, (size_t)counts[p] * ncols, dt, p, r.comm, st));
-      if (counts[r.rank] > 0 && (root < 0 || root == p))
-        SS_NCCL(r.Send(local, (size_t)counts[r.rank] * ncols, dt, p, r.comm, st));
+      if (receives && counts[p] > 0) {
+        bad = r.Recv(static_cast<char*>(full) + start * ncols * elem, (size_t)counts[p] * ncols, dt, p, r.comm, st);
+        what = "ncclRecv";
+      }
+      if (bad == NCCL_SUCCESS && counts[r.rank] > 0 && (root < 0 || root == p)) {
+        bad = r.Send(local, (size_t)counts[r.rank] * ncols, dt, p, r.comm, st);
+        what = "ncclSend";
+      }
     }
     start += counts[p];
   }
-  SS_NCCL(r.GroupEnd());
+  const int end = r.GroupEnd();
+  if (bad != NCCL_SUCCESS) return fail(SS_EHIP, "%s inside the gather group -> %s", what, r.GetErrorString(bad));
+  if (end != NCCL_SUCCESS) return fail(SS_EHIP, "ncclGroupEnd -> %s", r.GetErrorString(end));
   (void)total;
   return SS_OK;
 }

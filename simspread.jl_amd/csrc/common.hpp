@@ -47,6 +47,8 @@ struct Timing {
   bool dirty = false;
   bool hold = false;  // ss_timing_hold: calls accumulate instead of replacing one another
   unsigned generation = 0;
+  Timing();   // every thread's Timing is listed in a registry, so that ss_shutdown can destroy the events of ALL threads
+  ~Timing();  // thread exit: destroy this thread's events (if their context is still alive) and leave the registry
 };
 
 struct Ctx {

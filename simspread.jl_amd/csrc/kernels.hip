@@ -476,7 +476,8 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
   V* tile = reinterpret_cast<V*>(smem_raw);  // [KC + 1]; entry KC stays zero (padding target)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int64_t b0 = (int64_t)blockIdx.x * QT;
-  if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw != 0u) __builtin_trap();
+  // (the gathers below use tile-relative LDS addresses: the dynamic LDS segment must start at LDS address 0, i.e. the
+  // kernel must have no static __shared__ object -- launch_spmm_sell checks that on the host before the first launch)
 
   for (int c = 0; c < a.nchunks; ++c) {
     const int64_t k0 = (int64_t)c * a.KC;
@@ -651,17 +652,27 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
   }
   const dim3 grid(gx, gy);
   static std::atomic<bool> attr_set[2] = {{false}, {false}};
+  // first launch of an instantiation: raise its dynamic-LDS limit and check, on the host, what the kernel's LDS
+  // addressing relies on -- no static LDS in the code object's kernel, so that the dynamic segment starts at 0.
+  // (A violated assumption is an error code for the caller, never a device-side abort.)
+  auto prepare = [](const void* fn) -> int {
+    hipFuncAttributes fa{};
+    SS_HIP(hipFuncGetAttributes(&fa, fn));
+    if (fa.sharedSizeBytes != 0)
+      return fail(SS_EUNSUPPORTED, "spmm_sell_kernel was built with %zu bytes of static LDS: its tile-relative LDS "
+                  "addresses need the dynamic segment at LDS address 0", (size_t)fa.sharedSizeBytes);
+    SS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return SS_OK;
+  };
   if (W.binary) {
     if (!attr_set[0]) {
-      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SS_TRY(prepare(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, true>)));
       attr_set[0] = true;
     }
     hipLaunchKernelGGL((spmm_sell_kernel<T, QT, true>), grid, dim3(SELL_THREADS), lds, ctx().stream, a);
   } else {
     if (!attr_set[1]) {
-      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SS_TRY(prepare(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, false>)));
       attr_set[1] = true;
     }
     hipLaunchKernelGGL((spmm_sell_kernel<T, QT, false>), grid, dim3(SELL_THREADS), lds, ctx().stream, a);

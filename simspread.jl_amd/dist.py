@@ -130,6 +130,9 @@ def lib_gather_scores(local, counts: Sequence[int], root: Optional[int] = None):
     from . import _lib as L
     if not (local.is_cuda and local.is_contiguous()):
         raise TypeError("local must be a contiguous CUDA tensor")
+    # `local` was produced on torch's stream and `full` is allocated by torch: the exchange must be enqueued on that same
+    # stream, or nothing orders it behind the kernels that wrote `local`
+    L.use_torch_stream()
     rank, nranks = C.c_int(), C.c_int()
     L.check(L.lib().ss_comm_info(C.byref(rank), C.byref(nranks)))
     if nranks.value > 0 and (nranks.value != len(counts) or counts[rank.value] != local.shape[0]):

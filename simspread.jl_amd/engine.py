@@ -191,8 +191,20 @@ class DeviceGraph:
         pq, ldq, nq = dense_cm(Sq)
         ps, lds, ns = dense_cm(Ss)
         if dev:
+            import torch
             yp, yi, yv = Y[0], Y[1], Y[2]
             nt = int(Y[3])
+            # the ABI reads raw pointers: a tensor of another type would be reinterpreted silently -- convert (and keep
+            # the converted tensors alive until the constructor has copied them)
+            want = torch.float32 if dt == np.float32 else torch.float64
+            if not (yp.is_cuda and yi.is_cuda and (yv is None or yv.is_cuda)):
+                raise TypeError("device input: Y = (ptr, idx, val, nt) must be CUDA tensors")
+            yp = yp.to(torch.int64).contiguous()
+            yi = yi.to(torch.int32).contiguous()
+            yv = None if yv is None else yv.to(want).contiguous()
+            if yp.numel() != ns + 1:
+                raise AssertionError("Labels and features have different number of source nodes")
+            keep.extend([yp, yi, yv])
             yptr, yidx, yval = yp.data_ptr(), yi.data_ptr(), (None if yv is None else yv.data_ptr())
             mem = L.SS_MEM_DEVICE
         else:

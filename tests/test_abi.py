@@ -81,3 +81,19 @@ def test_entry_points_are_safe_from_several_threads_without_a_device():
     assert not any(t.is_alive() for t in threads), "deadlock"
     assert not errors, errors[:3]
     assert "ss_init" in msgs[0] and "ss_path_last" in msgs[1]
+
+
+def test_no_device_side_abort_in_any_kernel_source():
+    """include/simspread_hip.h promises that no entry point throws or aborts: a violated kernel assumption must be a
+    host-side check that returns an SS_E* code (e.g. the static-LDS check in launch_spmm_sell), never a trap on the GPU."""
+    import re
+    root = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")
+    bad = []
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".hpp")):
+            with open(os.path.join(root, f)) as fh:
+                for ln, line in enumerate(fh, 1):
+                    code = line.split("//")[0]
+                    if re.search(r"__builtin_trap|\babort\s*\(|\bassert\s*\(|__assert_fail|std::terminate|\bthrow\b", code):
+                        bad.append(f"{f}:{ln}: {line.strip()}")
+    assert not bad, bad

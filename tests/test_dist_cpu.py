@@ -97,6 +97,77 @@ def test_two_rank_gloo_sharded_predict_and_gather(tmp_path):
         np.testing.assert_array_equal(np.load(tmp_path / f"topv_{r}.npy"), np.take_along_axis(want, order, axis=1))
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start its two ranks itself (fresh children of
+    torch.distributed.run, created before the parent touches a GPU) and hand rank 0's JSON line through; here the ranks
+    only rendezvous over gloo on the CPU (--rendezvous-only), which is the whole launch path minus the device work."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0])["rendezvous"] == {"world": 2, "sum_of_rank_plus_1": 3, "gpus_arg": 2}
+
+
+def test_bench_self_launch_hands_back_the_exit_code():
+    """A failing rank must surface as a non-zero exit code of the plain command (no silent rc 0)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--no-such-flag"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+
+
+def _lib_gather_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import simspread_jl_amd as ss
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # only the 128-byte id travels over this
+    ss.init(rank)
+    ss.use_torch_stream()
+    ids = [ss.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ss.comm_init(ids[0], rank, world)
+    counts = [5, 3] if world == 2 else [5 + r for r in range(world)]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + rank)
+    for dtype in (torch.float32, torch.float64):
+        local = torch.rand((counts[rank], 257), device="cuda", dtype=dtype, generator=g)
+        full = ss.lib_gather_scores(local, counts)
+        at_root = ss.lib_gather_scores(local, counts, root=world - 1)
+        assert (at_root is None) == (rank != world - 1)
+        if at_root is not None:
+            assert torch.equal(at_root, full)
+        np.save(os.path.join(tmp, f"lib_{dtype}_{rank}.npy".replace("torch.", "")), full.cpu().numpy())
+        np.save(os.path.join(tmp, f"loc_{dtype}_{rank}.npy".replace("torch.", "")), local.cpu().numpy())
+    ss.comm_destroy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_process_library_rccl_gather_uneven_counts(tmp_path):
+    """The in-library gather (ss_gather_rows_*, comm.hip) with two ranks on two devices: uneven row counts, all ranks
+    receiving and root-only, fp32 and fp64.  Needs two GPUs (RCCL refuses two ranks on one device): skipped on the
+    one-GPU boxes, runs wherever the suite meets a multi-GPU node; bench.py --gpus N runs the same exchange by default."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL does not run two ranks on one device")
+    mp.spawn(_lib_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for dt in ("float32", "float64"):
+        want = np.concatenate([np.load(tmp_path / f"loc_{dt}_{r}.npy") for r in range(2)])
+        for r in range(2):
+            assert np.array_equal(np.load(tmp_path / f"lib_{dt}_{r}.npy"), want)
+
+
 @pytest.mark.gpu
 def test_two_rank_hip_path_equals_single_process_bit_for_bit(tmp_path):
     """The N > 1 path with the HIP kernels on every rank (two processes sharing the box's one GPU, gloo for the

@@ -133,3 +133,32 @@ def test_config4_ring_kernel_auto_selected(n):
         assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (n, alpha, weighted)
         assert ((want == -99) == (got == -99)).all()
         g.close()
+
+
+def test_config4_fp64_dense_path_at_20k():
+    """The fp64 dense-similarity kernel (dense_f64.hip, v_mfma_f64_16x16x4_f64) at the shape profiles/ quotes it on:
+    20k sources x 4096 folds = 1250 K-steps of 16 per tile, routed by the constructor (not forced), both weightings at
+    the 90 % fill of the named regime plus the sparse end; sampled folds against the fp64 oracle to 1e-12."""
+    import torch
+    from tools.c3_loo import rand_csr
+    from tools.c4_dense import measured_fill, sym_uniform
+    n, nt, folds, lo = 20_000, 10_000, 4096, 3000
+    gen = torch.Generator(device="cuda"); gen.manual_seed(20250222 + 4)
+    S = sym_uniform(n, gen).double()
+    yp, yi = rand_csr(n, nt, 0.01, gen)
+    Sh = S.cpu().numpy()
+    Y = _host_csr(yp, yi, None, (n, nt))
+    out = torch.empty((folds, nt), dtype=torch.float64, device="cuda")
+    for alpha, weighted in ((0.1, True), (0.1, False), (0.9, True)):
+        assert abs(measured_fill(S, alpha) - (1.0 - alpha)) < 2e-3
+        g = ss.DeviceGraph.from_similarity(None, S, (yp, yi, None, nt), alpha=alpha, weighted=weighted, dtype=np.float64)
+        g.predict_loo(lo, lo + folds, clean=True, out=out)
+        assert "transfer_dense_f64_mfma" in ss.path_last(), ss.path_last()
+        X = O.cutoff(Sh, alpha, weighted)
+        qs = [lo, lo + 2047, lo + folds - 1]
+        want = O.predict_loo_dense(X, Y, clean_flag=True, queries=qs)
+        del X
+        got = out[[q - lo for q in qs]].cpu().numpy()
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-12, (alpha, weighted)
+        assert ((want == -99) == (got == -99)).all()
+        g.close()
