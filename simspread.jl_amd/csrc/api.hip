@@ -472,10 +472,26 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
       } else if (kind == 2) {
         SS_TRY(launch_transfer_loo<T>(g.Xs, g.XsTc, g.kf.p, g.ks.p, row_begin + r0, nb, Tbuf.p, nj));
       } else if (kind == SS_ROWS_QUERY) {
-        const DevCsr<T>* L[2] = {&g.Xq, nullptr};
-        const DevChunked<T>* M[2] = {&g.XsTc, nullptr};
-        const T* inv1[2] = {g.inv_kf.p, nullptr};
-        SS_TRY(launch_transfer<T>(1, L, inv1, M, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj));
+        // query rows: SS_TRANSFER_V=2 selects the query-block kernels (measured variants of round 3)
+        // when the chunk's sub-row offsets fit in LDS next to >= 8 waves of accumulators; default: the single-wave kernel
+        const char* ev = getenv("SS_TRANSFER_V");
+        const bool want_block = (ev && atoi(ev) >= 2) && transfer_block_fits<T>(g.XsT.rows, g.XsTc.SC);
+        if (want_block) {
+          if (g.XsTb.SC == 0) {
+            int al = 32;
+            if (const char* e = getenv("SS_TRANSFER_ALIGN")) al = atoi(e) == 1 ? 1 : 32;
+            SS_TRY(chunked_build<T>(g.XsT, g.XsTc.SC, al, g.XsTb));
+          }
+          if (g.Cq.n < (size_t)(g.Xq.nnz > 0 ? g.Xq.nnz : 1)) SS_TRY(g.Cq.alloc((size_t)(g.Xq.nnz > 0 ? g.Xq.nnz : 1)));
+          const bool fixed = !(getenv("SS_TRANSFER_FIX") && atoi(getenv("SS_TRANSFER_FIX")) == 0);
+          SS_TRY(launch_transfer_block<T>(g.Xq, g.inv_kf.p, g.XsTb, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj, g.Cq.p,
+                                          1.0f, fixed));
+        } else {
+          const DevCsr<T>* L[2] = {&g.Xq, nullptr};
+          const DevChunked<T>* M[2] = {&g.XsTc, nullptr};
+          const T* inv1[2] = {g.inv_kf.p, nullptr};
+          SS_TRY(launch_transfer<T>(1, L, inv1, M, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj));
+        }
       } else {
         // source rows: feature path + target path
         const DevCsr<T>* L[2] = {&g.Xs, &g.Ys};

@@ -754,7 +754,7 @@ __global__ void chunk_fill_kernel(const int* __restrict__ ptr, const int* __rest
     b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
     const int n = a - first;
-    if (sched && align == 1 && n > 32 && n <= 64 * CHUNK_SCHED_ITERS) {
+    if (sched && n > 32 && n <= 64 * CHUNK_SCHED_ITERS) {
       // Bank schedule (stage-1 operand only).  The transfer kernel folds a sub-row into its LDS accumulators 64
       // entries per read-add-write, which the LDS serves in two groups of 32 lanes, one cycle per group when the
       // 32 addresses fall into different banks (bank = column mod 32) and one more for every extra address on a
@@ -802,6 +802,11 @@ __global__ void chunk_fill_kernel(const int* __restrict__ ptr, const int* __rest
           oval[o + pos] = val[first + lane + 64 * j];
         }
       }
+      // the scheduled entries occupy positions [0, n); padded sub-rows (align 32) end in zero entries
+      for (int x = n + lane; x < npad; x += 64) {
+        oidx[o + x] = (unsigned short)SC;
+        oval[o + x] = T(0);
+      }
       continue;
     }
     for (int x = lane; x < npad; x += 64) {
@@ -815,7 +820,7 @@ template <class T>
 int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out) {
   hipStream_t st = ctx().stream;
   if (SC < 1 || SC > 65535) return fail(SS_EINVAL, "chunk size out of range");
-  if (align != 1 && align != 4) return fail(SS_EINVAL, "chunk alignment must be 1 or 4");
+  if (align != 1 && align != 4 && align != 32) return fail(SS_EINVAL, "chunk alignment must be 1, 4 or 32");
   out.rows = in.rows;
   out.cols = in.cols;
   out.nnz = in.nnz;
@@ -848,8 +853,8 @@ int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out) {
   SS_TRY(out.val.alloc(out.stored + 64));
   SS_HIP(hipMemsetAsync(out.idx.p + out.stored, 0, 64 * sizeof(unsigned short), st));
   SS_HIP(hipMemsetAsync(out.val.p + out.stored, 0, 64 * sizeof(T), st));
-  // entry order inside a sub-row: bank-scheduled for the stage-1 operand (align 1) unless SS_CHUNK_SCHED=0
-  const int sched = (align == 1 && !(getenv("SS_CHUNK_SCHED") && atoi(getenv("SS_CHUNK_SCHED")) == 0)) ? 1 : 0;
+  // entry order inside a sub-row: bank-scheduled for the stage-1 operands (align 1 or 32) unless SS_CHUNK_SCHED=0
+  const int sched = ((align == 1 || align == 32) && !(getenv("SS_CHUNK_SCHED") && atoi(getenv("SS_CHUNK_SCHED")) == 0)) ? 1 : 0;
   hipLaunchKernelGGL(chunk_fill_kernel<T>, dim3(grid_for(total * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p,
                      in.val.p, in.rows, SC, out.nchunks, align, sched, out.off.p, out.idx.p, out.val.p);
   SS_LAUNCH_CHECK();

@@ -92,6 +92,8 @@ struct Graph {
   DevSell<T> W;
   int W_qt = 0;
   DevChunked<T> XsTc, YsTc;  // stage-1 operands (YsTc only for source rows), built lazily
+  DevChunked<T> XsTb;        // stage-1 operand of the query-block kernel (sub-rows padded to L2 sectors), built lazily
+  DevBuf<T> Cq;              // workspace of that kernel: Xq[r,a] * inv_kf[a], entry by entry
   DevBuf<T> Tws;  // workspace: rows of the transfer block T between stage 1 and stage 2
   DevBuf<T> Sws;  // workspace: sorted-order scores of a skew-sorted stage-2 operand
 };
@@ -149,6 +151,13 @@ template <class T>
 int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const DevChunked<T>* Mt[2],
                     const T* inv2, int64_t row_begin, int64_t nrows, int64_t nj, T* out, int64_t ld,
                     const int* row_ids = nullptr, bool accumulate = false);
+// stage 1 for plain query rows, query-block workgroups: sub-row offsets in LDS, coefficients precomputed into `coef`
+// (L.nnz values of workspace).  transfer_block_fits: whether offsets + >= 8 waves of accumulators fit in LDS.
+template <class T>
+int launch_transfer_block(const DevCsr<T>& L, const T* inv1, const DevChunked<T>& Mt, const T* inv2, int64_t row_begin,
+                          int64_t nrows, int64_t nj, T* out, int64_t ld, T* coef, float xmax, bool fixed);
+template <class T>
+bool transfer_block_fits(int64_t mrows, int SC);
 // k-fold: degrees / reciprocal degrees of the graph without the members of one fold
 template <class T>
 int launch_fold_degrees(const DevCsr<T>& X, const DevCsr<T>& XT, const DevCsr<T>& Y, const int* members,

@@ -13,6 +13,8 @@
 //
 // Wavefront = 64 lanes everywhere.  No float atomics anywhere: every sum has a fixed order, so
 // results are bitwise reproducible from run to run.
+#include <type_traits>
+
 #include "graph.hpp"
 
 namespace ss {
@@ -125,6 +127,7 @@ struct TransferArgs {
   T* out;
   int64_t ld;
   int accumulate;  // add to what `out` already holds (dense regime: the feature path came from the GEMM)
+  float xmax;      // FIX: largest |value| of the Mt operand
 };
 
 // One single-wave workgroup per (row r of L, column chunk c of T); c = blockIdx % nchunks so that,
@@ -248,7 +251,44 @@ __device__ __forceinline__ void subrows_fold(const SubRows<T, U>& s, int first, 
   }
 }
 
-template <class T, bool LOO, int U, bool BINM, bool DUAL>
+// Fixed-point fold (fp32 graphs): the product cf * v is scaled by 2^k (k per row of L, see transfer_block_kernel),
+// rounded to an integer and added with ds_add_u32.  An LDS integer atomic costs ~8 clk per wave-instruction on random
+// addresses where the plain read-add-write pair costs ~15 (tools/lds_atomic_bench.hip) -- and stage 1 runs at exactly
+// the LDS rate of its scatter -- it returns nothing (no wait, no dependent chain through the LDS round trip) and integer
+// addition commutes: the sums do not depend on any order, so the result is bitwise reproducible by construction.
+// Lanes past the end of a sub-row add 0 to whatever valid column they happened to read.
+__device__ __forceinline__ int cvt_rpi(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));   // floor(x + 0.5)
+  return r;
+}
+template <int U>
+__device__ __forceinline__ void subrows_fold_fixed(const SubRows<float, U>& s, int first, int b_l, int n_l, float cf_l,
+                                                   unsigned* __restrict__ acc, const unsigned short* __restrict__ midx,
+                                                   const float* __restrict__ mval, int lane) {
+  int nmax = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float v = lane < s.n[u] ? s.v[u] : 0.f;
+    atomicAdd(&acc[s.j[u]], (unsigned)cvt_rpi(s.cf[u] * v));
+    if (s.n[u] > 64) {
+      const float v2 = 64 + lane < s.n[u] ? s.v2[u] : 0.f;
+      atomicAdd(&acc[s.j2[u]], (unsigned)cvt_rpi(s.cf[u] * v2));
+    }
+    nmax = s.n[u] > nmax ? s.n[u] : nmax;
+  }
+  if (nmax > 128) {
+#pragma unroll 1
+    for (int u = 0; u < U; ++u) {
+      const int n = __builtin_amdgcn_readlane(n_l, first + u);
+      const unsigned b = (unsigned)__builtin_amdgcn_readlane(b_l, first + u);
+      const float cf = BitsOf<float>::bcast(cf_l, first + u);
+      for (int x = 128 + lane; x < n; x += 64) atomicAdd(&acc[midx[b + x]], (unsigned)cvt_rpi(cf * mval[b + x]));
+    }
+  }
+}
+
+template <class T, bool LOO, int U, bool BINM, bool DUAL, bool FIX = false>
 __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs<T> p) {
   static_assert(64 % (2 * U) == 0, "U must divide 32");
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -269,6 +309,7 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
     for (int j = lane; j < (p.SC + 31) / 32; j += 64) bits[j] = 0u;
   __syncthreads();
 
+  float fix_unscale = 1.f;
   for (int t = 0; t < p.nterms; ++t) {
     const CsrView<T> L = p.L[t];
     const ChunkedView<T> M = p.M[t];
@@ -276,6 +317,19 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
     const unsigned short* __restrict__ midx = M.idx;
     const T* __restrict__ mval = M.val;
     const int lb = L.ptr[gr], le = L.ptr[gr + 1];
+    float scale = 1.f;
+    if constexpr (FIX) {   // (experiment: fixed-point sums in the single-wave kernel; one term, not LOO)
+      float sabs = 0.f;
+      for (int q = lb + lane; q < le; q += 64) sabs += fabsf((float)(L.val[q] * p.inv1[t][L.idx[q]]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sabs += __shfl_xor(sabs, o);
+      int e = 0;
+      (void)frexpf(sabs * p.xmax, &e);
+      if (!(sabs * p.xmax > 0.f)) e = 0;
+      e = e < -90 ? -90 : (e > 120 ? 120 : e);
+      scale = ldexpf(1.f, 30 - e);
+      fix_unscale = ldexpf(1.f, e - 30);
+    }
     for (int g0 = lb; g0 < le; g0 += 64) {
       // ---- the next 64 neighbours a of r, one per lane: coefficient and sub-row bounds
       const int q = g0 + lane;
@@ -289,6 +343,7 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
           cf_l = (a != (int)gr && d > 0) ? lv * (T(1) / T(d)) : T(0);  // a == gr: the dropped feature
         } else {
           cf_l = lv * p.inv1[t][a];
+          if constexpr (FIX) cf_l = (T)((float)cf_l * scale);
         }
         if (cf_l != T(0)) { b_l = off[a]; n_l = off[a + 1] - b_l; }
       }
@@ -298,10 +353,12 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
       subrows_load<T, U, BINM>(A, 0, b_l, n_l, cf_l, midx, mval, lane);
       for (int u0 = 0; u0 < cnt; u0 += 2 * U) {
         if (u0 + U < cnt) subrows_load<T, U, BINM>(B, u0 + U, b_l, n_l, cf_l, midx, mval, lane);
-        subrows_fold<T, U, DUAL>(A, u0, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
+        if constexpr (FIX) subrows_fold_fixed<U>(A, u0, b_l, n_l, cf_l, reinterpret_cast<unsigned*>(acc), midx, mval, lane);
+        else subrows_fold<T, U, DUAL>(A, u0, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
         if (u0 + U < cnt) {
           if (u0 + 2 * U < cnt) subrows_load<T, U, BINM>(A, u0 + 2 * U, b_l, n_l, cf_l, midx, mval, lane);
-          subrows_fold<T, U, DUAL>(B, u0 + U, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
+          if constexpr (FIX) subrows_fold_fixed<U>(B, u0 + U, b_l, n_l, cf_l, reinterpret_cast<unsigned*>(acc), midx, mval, lane);
+          else subrows_fold<T, U, DUAL>(B, u0 + U, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
         }
       }
     }
@@ -320,7 +377,8 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
   T* orow = p.out + r * p.ld + j0;
   for (int j = lane; j < jn; j += 64) {
     T z;
-    const T sum = DUAL ? acc[j] + acc[astride + j] : acc[j];
+    T sum = DUAL ? acc[j] + acc[astride + j] : acc[j];
+    if constexpr (FIX) sum = (T)((float)reinterpret_cast<const int*>(acc)[j] * fix_unscale);
     if (LOO) {
       const int d = p.ks[j0 + j] - (int)((bits[j >> 5] >> (j & 31)) & 1u);
       z = (d > 0 && (j0 + j) != gr) ? sum * (T(1) / T(d)) : T(0);
@@ -346,6 +404,412 @@ static int transfer_u() {
   return (u == 4 || u == 16) ? u : 8;
 }
 
+// ---------------------------------------------------------------- stage 1, query-block workgroups (round 3)
+// Same product, same per-wave loop (U sub-rows in flight, plain LDS read-add-write), different workgroup: NW waves,
+// one row of L per wave, all on chunk c.  What the single-wave kernel fetched per (row, feature) from L2 besides the
+// sub-row itself -- off[a], off[a+1] (one 64-byte sector for 8 bytes) and inv1[a] (another sector for 4 bytes), i.e.
+// ~130 of the ~600 bytes of L2 -> L1 traffic per sub-row visit -- is gone: the chunk's sub-row offsets ((rows+1) ints)
+// are staged once per workgroup in LDS and read from there, and the coefficients L[r,a] * inv1[a] come from a
+// coalesced array written by transfer_coef_kernel (one pass over L per launch).  The operand may be cut with
+// sub-rows padded to 32 entries (64-byte index runs, 128-byte value runs: every sub-row starts on an L2 sector).
+template <class T>
+__global__ void transfer_coef_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const T* __restrict__ val,
+                                     const T* __restrict__ inv1, int64_t row_begin, int64_t nrows, T* __restrict__ coef) {
+  const int lo = ptr[row_begin], hi = ptr[row_begin + nrows];
+  for (int64_t e = (int64_t)lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < hi; e += (int64_t)gridDim.x * blockDim.x)
+    coef[e] = val[e] * inv1[idx[e]];
+}
+
+template <class T, int U, bool BINM, bool FIX, int K = 0>
+__global__ void __launch_bounds__(1024) transfer_block_kernel(TransferArgs<T> p, const T* __restrict__ coef, int64_t nrows,
+                                                              int align, int offs_bytes, float xmax) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  int* offs = reinterpret_cast<int*>(smem_raw);                               // [rows + 1] sub-row offsets of chunk c
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int astride = p.SC + 64;
+  T* acc = reinterpret_cast<T*>(smem_raw + offs_bytes) + (size_t)wave * astride;  // this wave's sums + per-lane dummies
+  const int c = blockIdx.x % p.nchunks;
+  const int64_t r = (int64_t)(blockIdx.x / p.nchunks) * nw + wave;
+  const ChunkedView<T> M = p.M[0];
+  const CsrView<T> L = p.L[0];
+  {
+    const int* __restrict__ off = M.off + (int64_t)c * M.rows;
+    for (int64_t i = threadIdx.x; i <= M.rows; i += blockDim.x) offs[i] = off[i];
+  }
+  for (int j = lane; j < astride; j += 64) acc[j] = T(0);
+  __syncthreads();
+  if (r >= nrows) return;   // (after the only barrier)
+  const int64_t gr = p.row_begin + r;
+  const int64_t j0 = (int64_t)c * p.SC;
+  const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
+  const int dummy = p.SC + lane;
+  const unsigned short* __restrict__ midx = M.idx;
+  const T* __restrict__ mval = M.val;
+  const int lb = L.ptr[gr], le = L.ptr[gr + 1];
+  // FIX: scale 2^k of this row's fixed-point sums.  Every sum is bounded by bound = (sum_a |coef[a]|) * xmax
+  // (xmax = largest |value| of the operand); bound < 2^e, so with k = 30 - e all sums stay below 2^30, the roundings
+  // (one unit per term at most) below 2^24: no overflow in 32 bits, resolution bound * 2^-30.
+  float scale = 1.f, unscale = 1.f;
+  if constexpr (FIX) {
+    float sabs = 0.f;
+    for (int q = lb + lane; q < le; q += 64) sabs += fabsf((float)coef[q]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sabs += __shfl_xor(sabs, o);
+    int e = 0;
+    (void)frexpf(sabs * xmax, &e);
+    if (!(sabs * xmax > 0.f)) e = 0;
+    e = e < -90 ? -90 : (e > 120 ? 120 : e);
+    scale = ldexpf(1.f, 30 - e);
+    unscale = ldexpf(1.f, e - 30);
+  }
+  if constexpr (K >= 2) {
+    // Flat software pipeline over ALL sub-rows of the row: a ring of K register sets of U sub-rows, K-1 sets' loads in
+    // flight while one set is folded in; the (index, coefficient) pairs of the 64-feature group after the next are in
+    // flight too, the sub-row bounds of the next group are looked up in LDS when the current one starts.  (The loop per
+    // 64-feature group exposes three dependent latencies at every group start and keeps only U sub-rows in flight:
+    // measured 280 clk per sub-row and wave at 2 waves per SIMD.)
+    static_assert((K - 1) * U <= 64 && 64 % U == 0, "ring must not reach past the next group");
+    const int len = le - lb;
+    auto raw_load = [&](int g, int& a, T& cf) __attribute__((always_inline)) {
+      const int q = lb + g * 64 + lane;
+      a = 0;
+      cf = T(0);
+      if (q < le) { a = L.idx[q]; cf = coef[q]; }
+    };
+    auto meta = [&](int a, T cf, int& b_l, int& n_l, T& cf_l) __attribute__((always_inline)) {
+      cf_l = cf;
+      if constexpr (FIX) cf_l = (T)((float)cf * scale);   // exact: a power of two
+      b_l = 0;
+      n_l = 0;
+      if (cf_l != T(0)) {
+        const int o0 = offs[a], o1 = offs[a + 1];
+        b_l = o0 * align;
+        n_l = (o1 - o0) * align;
+      }
+    };
+    int bc, nc, bn, nn, ra;
+    T cc, cn, rc;
+    raw_load(0, ra, rc); meta(ra, rc, bc, nc, cc);
+    raw_load(1, ra, rc); meta(ra, rc, bn, nn, cn);
+    raw_load(2, ra, rc);
+    int curg = 0;
+    SubRows<T, U> S[K];
+    auto load_at = [&](SubRows<T, U>& sr, int pa) __attribute__((always_inline)) {
+      const bool nx = (pa >> 6) != curg;   // wave-uniform: the position belongs to the next group
+      subrows_load<T, U, BINM>(sr, pa & 63, nx ? bn : bc, nx ? nn : nc, nx ? cn : cc, midx, mval, lane);
+    };
+    auto fold_at = [&](const SubRows<T, U>& sr, int pf) __attribute__((always_inline)) {
+      if constexpr (FIX) subrows_fold_fixed<U>(sr, pf & 63, bc, nc, cc, reinterpret_cast<unsigned*>(acc), midx, mval, lane);
+      else subrows_fold<T, U, false>(sr, pf & 63, bc, nc, cc, acc, astride, dummy, midx, mval, lane);
+    };
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k)
+      if (k * U < len) load_at(S[k], k * U);
+    for (int p0 = 0; p0 < len;) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int pa = p0 + (K - 1) * U;
+        if (pa < len) load_at(S[(k + K - 1) % K], pa);
+        if (p0 < len) fold_at(S[k], p0);
+        p0 += U;
+        if ((p0 & 63) == 0 && p0 < len) {   // the next group becomes the current one
+          bc = bn; nc = nn; cc = cn;
+          ++curg;
+          meta(ra, rc, bn, nn, cn);
+          raw_load(curg + 2, ra, rc);
+        }
+      }
+    }
+  } else
+  for (int g0 = lb; g0 < le; g0 += 64) {
+    const int q = g0 + lane;
+    int b_l = 0, n_l = 0;
+    T cf_l = T(0);
+    if (q < le) {
+      const int a = L.idx[q];
+      cf_l = coef[q];
+      if constexpr (FIX) cf_l = (T)((float)cf_l * scale);   // exact: a power of two
+      if (cf_l != T(0)) {
+        const int o0 = offs[a], o1 = offs[a + 1];
+        b_l = o0 * align;
+        n_l = (o1 - o0) * align;
+      }
+    }
+    const int cnt = __builtin_amdgcn_readfirstlane((le - g0 < 64) ? (le - g0) : 64);
+    SubRows<T, U> A, B;
+    subrows_load<T, U, BINM>(A, 0, b_l, n_l, cf_l, midx, mval, lane);
+    for (int u0 = 0; u0 < cnt; u0 += 2 * U) {
+      if (u0 + U < cnt) subrows_load<T, U, BINM>(B, u0 + U, b_l, n_l, cf_l, midx, mval, lane);
+      if constexpr (FIX) subrows_fold_fixed<U>(A, u0, b_l, n_l, cf_l, reinterpret_cast<unsigned*>(acc), midx, mval, lane);
+      else subrows_fold<T, U, false>(A, u0, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
+      if (u0 + U < cnt) {
+        if (u0 + 2 * U < cnt) subrows_load<T, U, BINM>(A, u0 + 2 * U, b_l, n_l, cf_l, midx, mval, lane);
+        if constexpr (FIX) subrows_fold_fixed<U>(B, u0 + U, b_l, n_l, cf_l, reinterpret_cast<unsigned*>(acc), midx, mval, lane);
+        else subrows_fold<T, U, false>(B, u0 + U, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
+      }
+    }
+  }
+  // the wave's own LDS operations execute in order: no barrier needed before it reads its sums back
+  T* orow = p.out + r * p.ld + j0;
+  if constexpr (FIX) {
+    const int* iacc = reinterpret_cast<const int*>(acc);
+    for (int j = lane; j < jn; j += 64) orow[j] = (T)((float)iacc[j] * unscale) * p.inv2[j0 + j];
+  } else {
+    for (int j = lane; j < jn; j += 64) orow[j] = acc[j] * p.inv2[j0 + j];
+  }
+}
+
+// ---------------------------------------------------------------- stage 1, piece ring (round 3)
+// The same workgroup as transfer_block_kernel (NW waves = NW rows of L on chunk c, sub-row offsets in LDS, coefficients
+// precomputed), with the row's work turned into ONE stream of "pieces" -- a piece = up to 64 consecutive entries of a
+// sub-row = exactly two loads (index, value) -- that runs through a ring of D register slots: D pieces' loads are in
+// flight while the oldest is folded in, across sub-rows, across the 64-feature groups and across the second halves of
+// long sub-rows (taken after the first halves of their group).  Every load of the ring is unconditional (the stream
+// ends in null pieces of 0 entries), so the compiler's vmcnt waits are exact counts.
+template <class T, int D, bool BINM, bool FIX>
+__global__ void __launch_bounds__(1024) transfer_ring_kernel(TransferArgs<T> p, const T* __restrict__ coef, int64_t nrows,
+                                                             int align, int offs_bytes, float xmax) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  int* offs = reinterpret_cast<int*>(smem_raw);
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it is wave-uniform
+  const int astride = p.SC + 64;
+  T* acc = reinterpret_cast<T*>(smem_raw + offs_bytes) + (size_t)wave * astride;
+  const int c = blockIdx.x % p.nchunks;
+  const int64_t r = (int64_t)(blockIdx.x / p.nchunks) * nw + wave;
+  const ChunkedView<T> M = p.M[0];
+  const CsrView<T> L = p.L[0];
+  {
+    const int* __restrict__ off = M.off + (int64_t)c * M.rows;
+    for (int64_t i = threadIdx.x; i <= M.rows; i += blockDim.x) offs[i] = off[i];
+  }
+  for (int j = lane; j < astride; j += 64) acc[j] = T(0);
+  __syncthreads();
+  if (r >= nrows) return;
+  const int64_t gr = p.row_begin + r;
+  const int64_t j0 = (int64_t)c * p.SC;
+  const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
+  const int dummy = p.SC + lane;
+  const unsigned short* __restrict__ midx = M.idx;
+  const T* __restrict__ mval = M.val;
+  const int lb = __builtin_amdgcn_readfirstlane(L.ptr[gr]), le = __builtin_amdgcn_readfirstlane(L.ptr[gr + 1]);
+  float scale = 1.f, unscale = 1.f;
+  if constexpr (FIX) {
+    float sabs = 0.f;
+    for (int q = lb + lane; q < le; q += 64) sabs += fabsf((float)coef[q]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sabs += __shfl_xor(sabs, o);
+    int e = 0;
+    (void)frexpf(sabs * xmax, &e);
+    if (!(sabs * xmax > 0.f)) e = 0;
+    e = e < -90 ? -90 : (e > 120 ? 120 : e);
+    scale = ldexpf(1.f, 30 - e);
+    unscale = ldexpf(1.f, e - 30);
+  }
+  const int ngroups = (le - lb + 63) >> 6;
+  // ---- metadata: raw (feature, coefficient) pairs of a 64-feature group, then its sub-row bounds from LDS
+  auto raw_load = [&](int g, int& a, T& cf) __attribute__((always_inline)) {
+    const int q = lb + g * 64 + lane;
+    a = 0;
+    cf = T(0);
+    if (q < le) { a = L.idx[q]; cf = coef[q]; }
+  };
+  auto meta = [&](int a, T cf, int& b_l, int& n_l, T& cf_l) __attribute__((always_inline)) {
+    cf_l = cf;
+    if constexpr (FIX) cf_l = (T)((float)cf * scale);
+    b_l = 0;
+    n_l = 0;
+    if (cf_l != T(0)) {
+      const int o0 = offs[a], o1 = offs[a + 1];
+      b_l = o0 * align;
+      n_l = (o1 - o0) * align;
+    }
+  };
+  int bc, nc, bn, nn, ra;   // current / next group: base and length of each lane's sub-row; raw features of the group after
+  T cc, cn, rc;
+  raw_load(0, ra, rc); meta(ra, rc, bc, nc, cc);
+  raw_load(1, ra, rc); meta(ra, rc, bn, nn, cn);
+  raw_load(2, ra, rc);
+  // ---- generator state (all wave-uniform): group, level h (entries 64h .. 64h+63 of the sub-rows), lanes still to take
+  int gcur = 0, h = 0;
+  unsigned long long todo = __ballot(nc > 0);
+  int live = 0;   // real pieces in the ring
+  // ring slots
+  unsigned short sj[D];
+  T sv[D];
+  int sn[D];
+  T scf[D];
+  auto next_piece = [&](unsigned short& oj, T& ov, int& on, T& ocf) __attribute__((always_inline)) {
+    // advance ONE step when the current (group, level) is used up (no loop: a step that lands on an empty level
+    // yields a null piece and the next call advances again)
+    if (todo == 0ull && gcur < ngroups) {
+      ++h;
+      todo = __ballot(nc > 64 * h);
+      if (todo == 0ull) {
+        ++gcur;
+        h = 0;
+        bc = bn; nc = nn; cc = cn;
+        meta(ra, rc, bn, nn, cn);
+        raw_load(gcur + 2, ra, rc);
+        todo = gcur < ngroups ? __ballot(nc > 0) : 0ull;
+      }
+    }
+    unsigned b = 0;
+    on = 0;
+    ocf = T(0);
+    if (todo != 0ull) {
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const int n = __builtin_amdgcn_readlane(nc, src) - 64 * h;
+      on = n < 64 ? n : 64;
+      b = (unsigned)__builtin_amdgcn_readlane(bc, src) + 64u * (unsigned)h;
+      ocf = BitsOf<T>::bcast(cc, src);
+      ++live;
+    }
+    oj = midx[b + lane];
+    ov = BINM ? T(1) : mval[b + lane];
+  };
+  auto fold = [&](unsigned short j, T v, int n, T cf) __attribute__((always_inline)) {
+    if constexpr (FIX) {
+      const float x = lane < n ? (float)v : 0.f;
+      atomicAdd(reinterpret_cast<unsigned*>(acc) + j, (unsigned)cvt_rpi((float)cf * x));
+    } else {
+      const int jj = lane < n ? (int)j : dummy;
+      acc[jj] = fma(cf, v, acc[jj]);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < D; ++i) next_piece(sj[i], sv[i], sn[i], scf[i]);
+  while (live > 0 || gcur < ngroups) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      fold(sj[i], sv[i], sn[i], scf[i]);
+      live -= sn[i] > 0 ? 1 : 0;
+      next_piece(sj[i], sv[i], sn[i], scf[i]);
+    }
+  }
+  T* orow = p.out + r * p.ld + j0;
+  if constexpr (FIX) {
+    const int* iacc = reinterpret_cast<const int*>(acc);
+    for (int j = lane; j < jn; j += 64) orow[j] = (T)((float)iacc[j] * unscale) * p.inv2[j0 + j];
+  } else {
+    for (int j = lane; j < jn; j += 64) orow[j] = acc[j] * p.inv2[j0 + j];
+  }
+}
+
+// waves per workgroup of the block kernel that fit next to the offsets: 0 = does not fit (fall back)
+template <class T>
+static int transfer_block_waves(int64_t mrows, int SC, int* offs_bytes) {
+  const int64_t ob = (((mrows + 1) * 4 + 15) / 16) * 16;
+  const int64_t per_wave = (int64_t)(SC + 64) * (int64_t)sizeof(T);
+  int64_t nw = ((int64_t)ctx().lds_per_block - ob) / per_wave;
+  if (ob >= (int64_t)ctx().lds_per_block) nw = 0;
+  if (nw > 16) nw = 16;
+  if (const char* e = getenv("SS_TRANSFER_NW")) {
+    const int v = atoi(e);
+    if (v >= 1 && v < nw) nw = v;
+  }
+  *offs_bytes = (int)ob;
+  return nw >= 8 ? (int)nw : 0;
+}
+
+template <class T>
+int launch_transfer_block(const DevCsr<T>& L, const T* inv1, const DevChunked<T>& Mt, const T* inv2, int64_t row_begin,
+                          int64_t nrows, int64_t nj, T* out, int64_t ld, T* coef, float xmax, bool fixed) {
+  if (nrows <= 0 || nj <= 0) return SS_OK;
+  int offs_bytes = 0;
+  const int nw = transfer_block_waves<T>(Mt.rows, Mt.SC, &offs_bytes);
+  if (nw == 0) return fail(SS_EUNSUPPORTED, "transfer_block: offsets + accumulators do not fit in LDS");
+  TransferArgs<T> p{};
+  p.nterms = 1;
+  p.L[0] = view(L);
+  p.M[0] = view(Mt);
+  p.inv2 = inv2;
+  p.row_begin = row_begin;
+  p.nj = nj;
+  p.SC = Mt.SC;
+  p.nchunks = Mt.nchunks;
+  p.out = out;
+  p.ld = ld;
+  const int64_t groups = ceil_div(nrows, (int64_t)nw);
+  const int64_t grid = groups * p.nchunks;
+  if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
+  path_add("transfer_block");
+  hipLaunchKernelGGL(transfer_coef_kernel<T>, dim3(grid_1d(L.nnz > 0 ? L.nnz : 1, 256, 256 * 8)), dim3(256), 0, ctx().stream,
+                     L.ptr.p, L.idx.p, L.val.p, inv1, row_begin, nrows, coef);
+  SS_LAUNCH_CHECK();
+  const size_t lds = (size_t)offs_bytes + (size_t)nw * (size_t)(p.SC + 64) * sizeof(T);
+  constexpr bool CANFIX = std::is_same<T, float>::value;
+  const bool fx = CANFIX && fixed;
+  if (fx) path_add("fixed_point");
+  // (U, K): sub-rows per register set, sets in the ring (K = 0: the loop per 64-feature group)
+  int pu = 8, pk = 3;
+  if (const char* e = getenv("SS_TRANSFER_PIPE")) {
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2) { pu = a; pk = b; }
+  }
+  int ring = 16;
+  if (const char* e = getenv("SS_TRANSFER_RING")) ring = atoi(e);
+#define SS_TR_LAUNCH(D, BINM, FIX)                                                                                    \
+  do {                                                                                                                \
+    static std::atomic<bool> attr_done{false};                                                                        \
+    if (!attr_done) {                                                                                                 \
+      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_ring_kernel<T, D, BINM, FIX>),               \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((transfer_ring_kernel<T, D, BINM, FIX>), dim3((unsigned)grid), dim3(64 * nw), lds,             \
+                       ctx().stream, p, (const T*)coef, nrows, Mt.align, offs_bytes, xmax);                           \
+  } while (0)
+#define SS_TR_BIN(D, FIX) do { if (Mt.binary) SS_TR_LAUNCH(D, true, FIX); else SS_TR_LAUNCH(D, false, FIX); } while (0)
+#define SS_TR_FIX(D) do { if (fx) SS_TR_BIN(D, CANFIX); else SS_TR_BIN(D, false); } while (0)
+  if (ring > 0) {
+    path_add("ring");
+    if (ring == 8) SS_TR_FIX(8);
+    else if (ring == 12) SS_TR_FIX(12);
+    else if (ring == 24) SS_TR_FIX(24);
+    else if (ring == 32) SS_TR_FIX(32);
+    else SS_TR_FIX(16);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+  }
+#undef SS_TR_FIX
+#undef SS_TR_BIN
+#undef SS_TR_LAUNCH
+#define SS_TB_LAUNCH(U, BINM, FIX, K)                                                                                 \
+  do {                                                                                                                \
+    static std::atomic<bool> attr_done{false};                                                                        \
+    if (!attr_done) {                                                                                                 \
+      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_block_kernel<T, U, BINM, FIX, K>),           \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((transfer_block_kernel<T, U, BINM, FIX, K>), dim3((unsigned)grid), dim3(64 * nw), lds,         \
+                       ctx().stream, p, (const T*)coef, nrows, Mt.align, offs_bytes, xmax);                           \
+  } while (0)
+#define SS_TB_BIN(U, FIX, K) do { if (Mt.binary) SS_TB_LAUNCH(U, true, FIX, K); else SS_TB_LAUNCH(U, false, FIX, K); } while (0)
+#define SS_TB_FIX(U, K) do { if (fx) SS_TB_BIN(U, CANFIX, K); else SS_TB_BIN(U, false, K); } while (0)
+  if (pu == 8 && pk == 0) SS_TB_FIX(8, 0);
+  else if (pu == 4 && pk == 0) SS_TB_FIX(4, 0);
+  else if (pu == 8 && pk == 2) SS_TB_FIX(8, 2);
+  else if (pu == 4 && pk == 4) SS_TB_FIX(4, 4);
+  else if (pu == 4 && pk == 6) SS_TB_FIX(4, 6);
+  else if (pu == 8 && pk == 4) SS_TB_FIX(8, 4);
+  else if (pu == 16 && pk == 2) SS_TB_FIX(16, 2);
+  else SS_TB_FIX(8, 3);
+#undef SS_TB_FIX
+#undef SS_TB_BIN
+#undef SS_TB_LAUNCH
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+template <class T>
+bool transfer_block_fits(int64_t mrows, int SC) {
+  int ob = 0;
+  return transfer_block_waves<T>(mrows, SC, &ob) > 0;
+}
+
 template <class T, bool LOO>
 static int launch_transfer_variant(const TransferArgs<T>& p, unsigned grid, size_t lds, bool binm, bool dual) {
 #define SS_TRANSFER_LAUNCH(U, BINM, DUAL)                                                               \
@@ -356,6 +820,21 @@ static int launch_transfer_variant(const TransferArgs<T>& p, unsigned grid, size
     if (binm) { if (dual) SS_TRANSFER_LAUNCH(U, true, true); else SS_TRANSFER_LAUNCH(U, true, false); } \
     else { if (dual) SS_TRANSFER_LAUNCH(U, false, true); else SS_TRANSFER_LAUNCH(U, false, false); }    \
   } while (0)
+  if constexpr (std::is_same<T, float>::value && !LOO) {
+    const char* e = getenv("SS_TRANSFER_FIX1");
+    if (e && atoi(e) == 1 && p.nterms == 1 && !dual && !p.accumulate) {
+      path_add("fixed_point");
+      if (transfer_u() == 4) {
+        if (binm) hipLaunchKernelGGL((transfer_kernel<T, LOO, 4, true, false, true>), dim3(grid), dim3(TRANSFER_THREADS), lds, ctx().stream, p);
+        else hipLaunchKernelGGL((transfer_kernel<T, LOO, 4, false, false, true>), dim3(grid), dim3(TRANSFER_THREADS), lds, ctx().stream, p);
+      } else {
+        if (binm) hipLaunchKernelGGL((transfer_kernel<T, LOO, 8, true, false, true>), dim3(grid), dim3(TRANSFER_THREADS), lds, ctx().stream, p);
+        else hipLaunchKernelGGL((transfer_kernel<T, LOO, 8, false, false, true>), dim3(grid), dim3(TRANSFER_THREADS), lds, ctx().stream, p);
+      }
+      SS_LAUNCH_CHECK();
+      return SS_OK;
+    }
+  }
   switch (transfer_u()) {
     case 4: SS_TRANSFER_U(4); break;
     case 16: SS_TRANSFER_U(16); break;
@@ -390,6 +869,7 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
   p.out = out;
   p.ld = ld;
   p.accumulate = accumulate ? 1 : 0;
+  p.xmax = 1.0f;
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
   bool binm = true;
@@ -1444,6 +1924,9 @@ int launch_jaccard(const T* F, int64_t n, int64_t d, int64_t ld, T* S, int64_t l
   template int launch_fold_degrees<T>(const DevCsr<T>&, const DevCsr<T>&, const DevCsr<T>&, const int*,     \
                                       int64_t, int*, int*, int*);                                           \
   template int launch_fold_inverse<T>(const int*, const int*, const int*, int, int64_t, int64_t, T*, T*);   \
+  template int launch_transfer_block<T>(const DevCsr<T>&, const T*, const DevChunked<T>&, const T*, int64_t, int64_t, \
+                                        int64_t, T*, int64_t, T*, float, bool);                               \
+  template bool transfer_block_fits<T>(int64_t, int);                                                        \
   template int launch_transfer_loo<T>(const DevCsr<T>&, const DevChunked<T>&, const int*, const int*,       \
                                       int64_t, int64_t, T*, int64_t);                                                \
   template int sell_max_chunk<T>(int);                                                                      \

@@ -16,7 +16,8 @@ import torch
 import simspread_jl_amd as ss
 from bench import synth_c2
 
-KEYS = ("SS_CHUNK_SCHED", "SS_TRANSFER_DUAL", "SS_TRANSFER_CHUNK", "SS_TRANSFER_U", "SS_TRANSFER_QB", "SS_TRANSFER_V")
+KEYS = ("SS_CHUNK_SCHED", "SS_TRANSFER_DUAL", "SS_TRANSFER_CHUNK", "SS_TRANSFER_U", "SS_TRANSFER_QB", "SS_TRANSFER_V",
+        "SS_TRANSFER_ALIGN", "SS_TRANSFER_NW", "SS_TRANSFER_X", "SS_TRANSFER_FIX", "SS_TRANSFER_FIX1", "SS_TRANSFER_PIPE", "SS_TRANSFER_RING")
 
 
 def main():
@@ -28,7 +29,8 @@ def main():
     ss.use_torch_stream()
     Xq, Xs, Ys = synth_c2(n, n, n, n, 0.05, 0.01, seed=20250222 + 2, rank=0, weighted=weighted)
     ref = None
-    for v in variants:
+    rounds = int(os.environ.get("ROUNDS", 1))   # ROUNDS > 1: the variants are run round-robin (same process), per-variant min / median
+    for v in variants * rounds:
         for k in KEYS:
             os.environ.pop(k, None)
         for kv in v.split():
@@ -45,7 +47,7 @@ def main():
         torch.cuda.synchronize()
         t = ss.timing_last()
         ss.timing_hold(False)
-        res = {"variant": v, "transfer_ms": round(t["transfer_ms"] / t["transfer_launches"], 4),
+        res = {"variant": v, "path": ",".join(ss.path_last()), "transfer_ms": round(t["transfer_ms"] / t["transfer_launches"], 4),
                "spmm_ms": round(t["spmm_ms"] / t["spmm_launches"], 4)}
         if ref is None:
             ref = out.clone()
