@@ -348,13 +348,12 @@ clean_ = clean  # Julia's `clean!`
 
 # --------------------------------------------------------------------------- split / save ("next" rows of SURVEY 8f)
 def split(y: NamedMatrix, k: int, seed: int = 1) -> List[List[str]]:
-    """k-fold grouping of the source names: shuffle, then source i (1-based) goes to fold mod(i, k) + 1
-    (src/core.jl:11-25).  The shuffle of the reference is Julia's MersenneTwister(seed) + shuffle!, which is
-    not reproduced bit for bit (its only test is skipped, test/runtests.jl:34: parity unpinned); numpy's
-    PCG64 is used instead, so the groups differ from Julia's for the same seed but have the same sizes."""
-    sources = list(y.names(1))
-    rng = np.random.default_rng(seed)
-    rng.shuffle(sources)
+    """k-fold grouping of the source names: ``shuffle!(MersenneTwister(seed), sources)``, then source i (1-based, in
+    shuffled order) goes to fold mod(i, k) + 1 (src/core.jl:11-25).  The shuffle is Julia's, bit for bit
+    (julia_rng.py: dSFMT-19937 + Random.shuffle!), so the groups are the reference's for the same seed -- pinned by the
+    reference's own expected grouping for seed 1, k 5 (test/runtests.jl:31-32)."""
+    from .julia_rng import shuffle
+    sources = shuffle(list(y.names(1)), seed)
     groups: List[List[str]] = [[] for _ in range(k)]
     for i, s in enumerate(sources, start=1):
         groups[i % k].append(s)

@@ -485,7 +485,7 @@ static int predict_rows_device(Graph<T>& g, int kind, int64_t row_begin, int64_t
           if (g.Cq.n < (size_t)(g.Xq.nnz > 0 ? g.Xq.nnz : 1)) SS_TRY(g.Cq.alloc((size_t)(g.Xq.nnz > 0 ? g.Xq.nnz : 1)));
           const bool fixed = !(getenv("SS_TRANSFER_FIX") && atoi(getenv("SS_TRANSFER_FIX")) == 0);
           SS_TRY(launch_transfer_block<T>(g.Xq, g.inv_kf.p, g.XsTb, g.inv_ks.p, row_begin + r0, nb, nj, Tbuf.p, nj, g.Cq.p,
-                                          1.0f, fixed));
+                                          g.XsTb.vmax, fixed));
         } else {
           const DevCsr<T>* L[2] = {&g.Xq, nullptr};
           const DevChunked<T>* M[2] = {&g.XsTc, nullptr};

@@ -711,10 +711,24 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   return SS_OK;
 }
 
+// largest and smallest non-zero |value| of an array, as fp32 bit patterns (non-negative floats order like integers)
+template <class T>
+__global__ void abs_range_kernel(const T* __restrict__ v, int64_t n, int* __restrict__ mm) {
+  int mx = 0, mn = 0x7f7fffff;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = fabsf((float)v[i]);
+    const int b = __float_as_int(a);
+    if (a > 0.f) { mx = b > mx ? b : mx; mn = b < mn ? b : mn; }
+  }
+  atomicMax(&mm[0], mx);
+  atomicMin(&mm[1], mn);
+}
+
 // ------------------------------------------------------------------ CSR -> column-chunked CSR (stage-1 operand)
 // one thread per (chunk, row): entries of the row inside the chunk
 __global__ void chunk_count_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, int64_t rows, int SC,
-                                   int nchunks, int align, int* __restrict__ cnt) {
+                                   int nchunks, int align, int* __restrict__ cnt, unsigned short* __restrict__ len16,
+                                   int* __restrict__ toolong) {
   const int64_t total = rows * nchunks;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i / rows);
@@ -727,6 +741,10 @@ __global__ void chunk_count_kernel(const int* __restrict__ ptr, const int* __res
     b = hi;
     while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
     cnt[i] = (a - first + align - 1) / align;  // in units of `align` entries
+    if (len16) {                               // exact entry count of the sub-row (the units only give the padded length)
+      len16[i] = (unsigned short)(a - first);
+      if (a - first > 65535) *toolong = 1;
+    }
   }
 }
 
@@ -840,19 +858,48 @@ int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out) {
   }
   DevBuf<int> cnt;
   SS_TRY(cnt.alloc(total));
+  DevBuf<int> toolong;
+  if (align == 32) {   // the flat-stream transfer kernel walks exact sub-row lengths (starts stay sector-aligned)
+    SS_TRY(out.len.alloc(total));
+    SS_TRY(toolong.alloc(1));
+    SS_HIP(hipMemsetAsync(toolong.p, 0, sizeof(int), st));
+  }
   hipLaunchKernelGGL(chunk_count_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p, in.rows, SC,
-                     out.nchunks, align, cnt.p);
+                     out.nchunks, align, cnt.p, align == 32 ? out.len.p : (unsigned short*)nullptr,
+                     align == 32 ? toolong.p : (int*)nullptr);
   SS_LAUNCH_CHECK();
+  if (align == 32) {
+    int tl = 0;
+    SS_TRY(read_int(toolong.p, &tl));
+    out.len_ok = (tl == 0);
+  }
+  // range of the |values| (the fixed-point transfer kernel scales its sums by it)
+  {
+    DevBuf<int> mm;
+    SS_TRY(mm.alloc(2));
+    const int init[2] = {0, 0x7f7fffff};
+    SS_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    if (in.nnz > 0) {
+      hipLaunchKernelGGL(abs_range_kernel<T>, dim3(grid_for(in.nnz, 256)), dim3(256), 0, st, in.val.p, in.nnz, mm.p);
+      SS_LAUNCH_CHECK();
+    }
+    int got[2];
+    SS_HIP(hipMemcpyAsync(got, mm.p, sizeof(got), hipMemcpyDeviceToHost, st));
+    SS_HIP(hipStreamSynchronize(st));
+    memcpy(&out.vmax, &got[0], 4);
+    memcpy(&out.vmin, &got[1], 4);
+    if (in.nnz == 0) out.vmax = out.vmin = 0.f;
+  }
   SS_TRY(exclusive_scan_int(cnt.p, out.off.p, total));
   int units = 0;
   SS_TRY(read_int(out.off.p + total, &units));
   if (units < 0 || (int64_t)units * align >= (1LL << 31) - 64) return fail(SS_EUNSUPPORTED, "chunked operand too large");
   out.stored = (int64_t)units * align;
-  // 64 entries of slack: the transfer kernel loads whole waves past the end of a sub-row
-  SS_TRY(out.idx.alloc(out.stored + 64));
-  SS_TRY(out.val.alloc(out.stored + 64));
-  SS_HIP(hipMemsetAsync(out.idx.p + out.stored, 0, 64 * sizeof(unsigned short), st));
-  SS_HIP(hipMemsetAsync(out.val.p + out.stored, 0, 64 * sizeof(T), st));
+  // 256 entries of slack: the transfer kernels load whole waves (up to 16 bytes per lane) past the end of a sub-row
+  SS_TRY(out.idx.alloc(out.stored + 256));
+  SS_TRY(out.val.alloc(out.stored + 256));
+  SS_HIP(hipMemsetAsync(out.idx.p + out.stored, 0, 256 * sizeof(unsigned short), st));
+  SS_HIP(hipMemsetAsync(out.val.p + out.stored, 0, 256 * sizeof(T), st));
   // entry order inside a sub-row: bank-scheduled for the stage-1 operands (align 1 or 32) unless SS_CHUNK_SCHED=0
   const int sched = ((align == 1 || align == 32) && !(getenv("SS_CHUNK_SCHED") && atoi(getenv("SS_CHUNK_SCHED")) == 0)) ? 1 : 0;
   hipLaunchKernelGGL(chunk_fill_kernel<T>, dim3(grid_for(total * 64, 256)), dim3(256), 0, st, in.ptr.p, in.idx.p,

@@ -58,6 +58,9 @@ struct DevChunked {
   DevBuf<int> off;             // [nchunks*rows + 1]
   DevBuf<unsigned short> idx;  // [stored + 64]
   DevBuf<T> val;               // [stored + 64]
+  DevBuf<unsigned short> len;  // align 32 only: exact entry count of every sub-row [nchunks*rows]
+  bool len_ok = false;         //   ... all of them < 65536
+  float vmax = 0.f, vmin = 0.f;  // largest / smallest non-zero |value|
 };
 
 // Dense-similarity regime: the raw similarities stay dense on the device (column-major), the cutoff is

@@ -171,6 +171,28 @@ struct SubRows {
   T v2[U];
 };
 
+// The same loads as buffer instructions: resource descriptor (SGPRs) + scalar byte offset of the sub-row + a 32-bit lane
+// offset.  A global_load with per-lane 64-bit addresses hands the texture addresser 512 bytes of address per
+// wave-instruction, the buffer form 256; stage 1 is bound by that unit (TA busy 92 % of the kernel at ~7 clk per load,
+// profiles/r03_stage1_mem_pmc.txt).
+template <int U, bool BINM>
+__device__ __forceinline__ void subrows_load_buf(SubRows<float, U>& s, int first, int b_l, int n_l, float cf_l,
+                                                 __amdgpu_buffer_rsrc_t ridx, __amdgpu_buffer_rsrc_t rval, int lane) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int src = first + u;
+    s.b[u] = (unsigned)__builtin_amdgcn_readlane(b_l, src);
+    s.n[u] = __builtin_amdgcn_readlane(n_l, src);
+    s.cf[u] = BitsOf<float>::bcast(cf_l, src);
+    s.j[u] = __builtin_amdgcn_raw_buffer_load_b16(ridx, lane * 2, (int)(s.b[u] * 2u), 0);
+    s.v[u] = BINM ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rval, lane * 4, (int)(s.b[u] * 4u), 0));
+    if (s.n[u] > 64) {
+      s.j2[u] = __builtin_amdgcn_raw_buffer_load_b16(ridx, lane * 2, (int)(s.b[u] * 2u + 128u), 0);
+      s.v2[u] = BINM ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rval, lane * 4, (int)(s.b[u] * 4u + 256u), 0));
+    }
+  }
+}
+
 template <class T, int U, bool BINM>
 __device__ __forceinline__ void subrows_load(SubRows<T, U>& s, int first, int b_l, int n_l, T cf_l,
                                              const unsigned short* __restrict__ midx, const T* __restrict__ mval,
@@ -288,7 +310,7 @@ __device__ __forceinline__ void subrows_fold_fixed(const SubRows<float, U>& s, i
   }
 }
 
-template <class T, bool LOO, int U, bool BINM, bool DUAL, bool FIX = false>
+template <class T, bool LOO, int U, bool BINM, bool DUAL, bool FIX = false, bool BUF = false>
 __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs<T> p) {
   static_assert(64 % (2 * U) == 0, "U must divide 32");
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -350,13 +372,22 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
       const int cnt = __builtin_amdgcn_readfirstlane((le - g0 < 64) ? (le - g0) : 64);
       // ---- fold the sub-rows in, U at a time; the loads of the next U are in flight meanwhile
       SubRows<T, U> A, B;
-      subrows_load<T, U, BINM>(A, 0, b_l, n_l, cf_l, midx, mval, lane);
+      auto load = [&](SubRows<T, U>& sr, int first) __attribute__((always_inline)) {
+        if constexpr (BUF) {
+          const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc((void*)midx, 0, -1, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rval = __builtin_amdgcn_make_buffer_rsrc((void*)mval, 0, -1, 0x00020000);
+          subrows_load_buf<U, BINM>(sr, first, b_l, n_l, cf_l, ridx, rval, lane);
+        } else {
+          subrows_load<T, U, BINM>(sr, first, b_l, n_l, cf_l, midx, mval, lane);
+        }
+      };
+      load(A, 0);
       for (int u0 = 0; u0 < cnt; u0 += 2 * U) {
-        if (u0 + U < cnt) subrows_load<T, U, BINM>(B, u0 + U, b_l, n_l, cf_l, midx, mval, lane);
+        if (u0 + U < cnt) load(B, u0 + U);
         if constexpr (FIX) subrows_fold_fixed<U>(A, u0, b_l, n_l, cf_l, reinterpret_cast<unsigned*>(acc), midx, mval, lane);
         else subrows_fold<T, U, DUAL>(A, u0, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
         if (u0 + U < cnt) {
-          if (u0 + 2 * U < cnt) subrows_load<T, U, BINM>(A, u0 + 2 * U, b_l, n_l, cf_l, midx, mval, lane);
+          if (u0 + 2 * U < cnt) load(A, u0 + 2 * U);
           if constexpr (FIX) subrows_fold_fixed<U>(B, u0 + U, b_l, n_l, cf_l, reinterpret_cast<unsigned*>(acc), midx, mval, lane);
           else subrows_fold<T, U, DUAL>(B, u0 + U, b_l, n_l, cf_l, acc, astride, dummy, midx, mval, lane);
         }
@@ -420,7 +451,7 @@ __global__ void transfer_coef_kernel(const int* __restrict__ ptr, const int* __r
     coef[e] = val[e] * inv1[idx[e]];
 }
 
-template <class T, int U, bool BINM, bool FIX, int K = 0>
+template <class T, int U, bool BINM, bool FIX>
 __global__ void __launch_bounds__(1024) transfer_block_kernel(TransferArgs<T> p, const T* __restrict__ coef, int64_t nrows,
                                                               int align, int offs_bytes, float xmax) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -462,65 +493,6 @@ __global__ void __launch_bounds__(1024) transfer_block_kernel(TransferArgs<T> p,
     scale = ldexpf(1.f, 30 - e);
     unscale = ldexpf(1.f, e - 30);
   }
-  if constexpr (K >= 2) {
-    // Flat software pipeline over ALL sub-rows of the row: a ring of K register sets of U sub-rows, K-1 sets' loads in
-    // flight while one set is folded in; the (index, coefficient) pairs of the 64-feature group after the next are in
-    // flight too, the sub-row bounds of the next group are looked up in LDS when the current one starts.  (The loop per
-    // 64-feature group exposes three dependent latencies at every group start and keeps only U sub-rows in flight:
-    // measured 280 clk per sub-row and wave at 2 waves per SIMD.)
-    static_assert((K - 1) * U <= 64 && 64 % U == 0, "ring must not reach past the next group");
-    const int len = le - lb;
-    auto raw_load = [&](int g, int& a, T& cf) __attribute__((always_inline)) {
-      const int q = lb + g * 64 + lane;
-      a = 0;
-      cf = T(0);
-      if (q < le) { a = L.idx[q]; cf = coef[q]; }
-    };
-    auto meta = [&](int a, T cf, int& b_l, int& n_l, T& cf_l) __attribute__((always_inline)) {
-      cf_l = cf;
-      if constexpr (FIX) cf_l = (T)((float)cf * scale);   // exact: a power of two
-      b_l = 0;
-      n_l = 0;
-      if (cf_l != T(0)) {
-        const int o0 = offs[a], o1 = offs[a + 1];
-        b_l = o0 * align;
-        n_l = (o1 - o0) * align;
-      }
-    };
-    int bc, nc, bn, nn, ra;
-    T cc, cn, rc;
-    raw_load(0, ra, rc); meta(ra, rc, bc, nc, cc);
-    raw_load(1, ra, rc); meta(ra, rc, bn, nn, cn);
-    raw_load(2, ra, rc);
-    int curg = 0;
-    SubRows<T, U> S[K];
-    auto load_at = [&](SubRows<T, U>& sr, int pa) __attribute__((always_inline)) {
-      const bool nx = (pa >> 6) != curg;   // wave-uniform: the position belongs to the next group
-      subrows_load<T, U, BINM>(sr, pa & 63, nx ? bn : bc, nx ? nn : nc, nx ? cn : cc, midx, mval, lane);
-    };
-    auto fold_at = [&](const SubRows<T, U>& sr, int pf) __attribute__((always_inline)) {
-      if constexpr (FIX) subrows_fold_fixed<U>(sr, pf & 63, bc, nc, cc, reinterpret_cast<unsigned*>(acc), midx, mval, lane);
-      else subrows_fold<T, U, false>(sr, pf & 63, bc, nc, cc, acc, astride, dummy, midx, mval, lane);
-    };
-#pragma unroll
-    for (int k = 0; k < K - 1; ++k)
-      if (k * U < len) load_at(S[k], k * U);
-    for (int p0 = 0; p0 < len;) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int pa = p0 + (K - 1) * U;
-        if (pa < len) load_at(S[(k + K - 1) % K], pa);
-        if (p0 < len) fold_at(S[k], p0);
-        p0 += U;
-        if ((p0 & 63) == 0 && p0 < len) {   // the next group becomes the current one
-          bc = bn; nc = nn; cc = cn;
-          ++curg;
-          meta(ra, rc, bn, nn, cn);
-          raw_load(curg + 2, ra, rc);
-        }
-      }
-    }
-  } else
   for (int g0 = lb; g0 < le; g0 += 64) {
     const int q = g0 + lane;
     int b_l = 0, n_l = 0;
@@ -559,44 +531,53 @@ __global__ void __launch_bounds__(1024) transfer_block_kernel(TransferArgs<T> p,
   }
 }
 
-// ---------------------------------------------------------------- stage 1, piece ring (round 3)
-// The same workgroup as transfer_block_kernel (NW waves = NW rows of L on chunk c, sub-row offsets in LDS, coefficients
-// precomputed), with the row's work turned into ONE stream of "pieces" -- a piece = up to 64 consecutive entries of a
-// sub-row = exactly two loads (index, value) -- that runs through a ring of D register slots: D pieces' loads are in
-// flight while the oldest is folded in, across sub-rows, across the 64-feature groups and across the second halves of
-// long sub-rows (taken after the first halves of their group).  Every load of the ring is unconditional (the stream
-// ends in null pieces of 0 entries), so the compiler's vmcnt waits are exact counts.
-template <class T, int D, bool BINM, bool FIX>
-__global__ void __launch_bounds__(1024) transfer_ring_kernel(TransferArgs<T> p, const T* __restrict__ coef, int64_t nrows,
-                                                             int align, int offs_bytes, float xmax) {
+// ---------------------------------------------------------------- stage 1, flat stream of quads (round 3, measured variant)
+// Workgroup as in transfer_block_kernel (NW waves = NW rows of L on chunk c; the chunk's sub-row offsets AND exact
+// sub-row lengths staged in LDS; coefficients precomputed).  The entries of the 64 sub-rows of a feature group are walked
+// as ONE stream of QUADS (4 consecutive entries of a sub-row, the last quad of a sub-row padded with zero entries) in
+// steps of 64 quads = 256 entries ~ four 62-entry sub-rows: lane l of step t takes stream position 64 t + l, whichever
+// sub-row it falls into -- no half-empty second halves.  One global_load_dwordx4 (values) + one global_load_dwordx2
+// (indices) per step; a step holds entries of several features, whose columns can coincide: only safe because the sums
+// are integer atomics (ds_add_u32 on 2^k-scaled fixed-point products, see subrows_fold_fixed).  Per step: the owner of
+// the first lane (popcount of a ballot), then one select per sub-row boundary inside the step, all from wave-uniform
+// broadcasts.  Steps run through a ring of D slots, every load unconditional.  Measured (C2): 2.04 ms -- the boundary
+// loop's readlane -> scalar -> select chains make a step ~1900 clk per wave.
+template <class T, int D, bool BINM>
+__global__ void __launch_bounds__(1024) transfer_qflat_kernel(TransferArgs<T> p, const T* __restrict__ coef, int64_t nrows,
+                                                             int align, int offs_bytes, int lens_bytes, float xmax,
+                                                             const unsigned short* __restrict__ glen) {
+  static_assert(std::is_same<T, float>::value, "fixed-point sums: fp32 graphs only");
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  int* offs = reinterpret_cast<int*>(smem_raw);
+  int* offs = reinterpret_cast<int*>(smem_raw);                                        // [rows + 1], units of `align`
+  unsigned short* lens = reinterpret_cast<unsigned short*>(smem_raw + offs_bytes);     // [rows] exact entries
   const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything derived from it is wave-uniform
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int astride = p.SC + 64;
-  T* acc = reinterpret_cast<T*>(smem_raw + offs_bytes) + (size_t)wave * astride;
+  unsigned* acc = reinterpret_cast<unsigned*>(smem_raw + offs_bytes + lens_bytes) + (size_t)wave * astride;
   const int c = blockIdx.x % p.nchunks;
   const int64_t r = (int64_t)(blockIdx.x / p.nchunks) * nw + wave;
   const ChunkedView<T> M = p.M[0];
   const CsrView<T> L = p.L[0];
   {
     const int* __restrict__ off = M.off + (int64_t)c * M.rows;
+    const unsigned short* __restrict__ gl = glen + (int64_t)c * M.rows;
     for (int64_t i = threadIdx.x; i <= M.rows; i += blockDim.x) offs[i] = off[i];
+    for (int64_t i = threadIdx.x; i < M.rows; i += blockDim.x) lens[i] = gl[i];
   }
-  for (int j = lane; j < astride; j += 64) acc[j] = T(0);
+  for (int j = lane; j < astride; j += 64) acc[j] = 0u;
   __syncthreads();
   if (r >= nrows) return;
   const int64_t gr = p.row_begin + r;
   const int64_t j0 = (int64_t)c * p.SC;
   const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
-  const int dummy = p.SC + lane;
   const unsigned short* __restrict__ midx = M.idx;
   const T* __restrict__ mval = M.val;
   const int lb = __builtin_amdgcn_readfirstlane(L.ptr[gr]), le = __builtin_amdgcn_readfirstlane(L.ptr[gr + 1]);
-  float scale = 1.f, unscale = 1.f;
-  if constexpr (FIX) {
+  // scale 2^k of the row's sums: bound = (sum |coef|) * xmax < 2^e, k = 30 - e (see transfer_block_kernel)
+  float scale, unscale;
+  {
     float sabs = 0.f;
-    for (int q = lb + lane; q < le; q += 64) sabs += fabsf((float)coef[q]);
+    for (int q = lb + lane; q < le; q += 64) sabs += fabsf(coef[q]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sabs += __shfl_xor(sabs, o);
     int e = 0;
@@ -607,94 +588,450 @@ __global__ void __launch_bounds__(1024) transfer_ring_kernel(TransferArgs<T> p, 
     unscale = ldexpf(1.f, e - 30);
   }
   const int ngroups = (le - lb + 63) >> 6;
-  // ---- metadata: raw (feature, coefficient) pairs of a 64-feature group, then its sub-row bounds from LDS
-  auto raw_load = [&](int g, int& a, T& cf) __attribute__((always_inline)) {
+  auto raw_load = [&](int g, int& a, float& cf) __attribute__((always_inline)) {
     const int q = lb + g * 64 + lane;
     a = 0;
-    cf = T(0);
+    cf = 0.f;
     if (q < le) { a = L.idx[q]; cf = coef[q]; }
   };
-  auto meta = [&](int a, T cf, int& b_l, int& n_l, T& cf_l) __attribute__((always_inline)) {
-    cf_l = cf;
-    if constexpr (FIX) cf_l = (T)((float)cf * scale);
+  // sub-row of feature a in this chunk: start (entries) and exact length, from LDS; nothing for a zero coefficient
+  auto meta = [&](int a, float cf, int& b_l, int& n_l, float& cf_l) __attribute__((always_inline)) {
+    cf_l = cf * scale;   // exact: a power of two
     b_l = 0;
     n_l = 0;
-    if (cf_l != T(0)) {
-      const int o0 = offs[a], o1 = offs[a + 1];
-      b_l = o0 * align;
-      n_l = (o1 - o0) * align;
+    if (cf_l != 0.f) {
+      b_l = (offs[a] * align) >> 2;        // start in quads (sub-rows start on 32-entry boundaries)
+      n_l = ((int)lens[a] + 3) >> 2;       // length in quads; the last quad is padded with zero entries
     }
   };
-  int bc, nc, bn, nn, ra;   // current / next group: base and length of each lane's sub-row; raw features of the group after
-  T cc, cn, rc;
-  raw_load(0, ra, rc); meta(ra, rc, bc, nc, cc);
-  raw_load(1, ra, rc); meta(ra, rc, bn, nn, cn);
-  raw_load(2, ra, rc);
-  // ---- generator state (all wave-uniform): group, level h (entries 64h .. 64h+63 of the sub-rows), lanes still to take
-  int gcur = 0, h = 0;
-  unsigned long long todo = __ballot(nc > 0);
-  int live = 0;   // real pieces in the ring
-  // ring slots
-  unsigned short sj[D];
-  T sv[D];
-  int sn[D];
-  T scf[D];
-  auto next_piece = [&](unsigned short& oj, T& ov, int& on, T& ocf) __attribute__((always_inline)) {
-    // advance ONE step when the current (group, level) is used up (no loop: a step that lands on an empty level
-    // yields a null piece and the next call advances again)
-    if (todo == 0ull && gcur < ngroups) {
-      ++h;
-      todo = __ballot(nc > 64 * h);
-      if (todo == 0ull) {
-        ++gcur;
-        h = 0;
-        bc = bn; nc = nn; cc = cn;
-        meta(ra, rc, bn, nn, cn);
-        raw_load(gcur + 2, ra, rc);
-        todo = gcur < ngroups ? __ballot(nc > 0) : 0ull;
+  // current group: per lane i the stream start P_i of its sub-row, delta_i = start in memory - P_i, coefficient
+  int Pc = 0, dc = 0, ra, bn, nn;
+  float cc = 0.f, cn, rc;
+  int total = 0, nst = 0, t = 0, gcur = -1;
+  raw_load(0, ra, rc); meta(ra, rc, bn, nn, cn);
+  raw_load(1, ra, rc);
+  bool done = false;
+  auto switch_group = [&]() __attribute__((always_inline)) {
+    // the prepared next group becomes current: exclusive prefix sum of the lengths over the 64 lanes
+    ++gcur;
+    int incl = nn;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    Pc = incl - nn;
+    dc = bn - Pc;
+    cc = cn;
+    total = __builtin_amdgcn_readlane(incl, 63);
+    nst = (total + 63) >> 6;
+    t = 0;
+    meta(ra, rc, bn, nn, cn);            // group gcur + 1 (its raw pairs were requested a group ago)
+    raw_load(gcur + 2, ra, rc);
+  };
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  u2 sj[D];
+  f4 sv[D];
+  float sc[D];
+  const f4* __restrict__ mval4 = reinterpret_cast<const f4*>(mval);
+  const u2* __restrict__ midx4 = reinterpret_cast<const u2*>(midx);
+  auto next_step = [&](u2& oj, f4& ov, float& ocf) __attribute__((always_inline)) {
+    if (t >= nst) {
+      if (gcur + 1 < ngroups) switch_group();   // (may land on a group without entries: a null step, next call moves on)
+      else done = true;
+    }
+    float cfv = 0.f;
+    int addr = lane;   // lanes without work add 0 to different columns (same-address atomics serialise)
+    if (t < nst) {
+      const int lo = t << 6;
+      const int pos = lo + lane;
+      const unsigned long long le_mask = __ballot(Pc <= lo);
+      const int own0 = __builtin_popcountll(le_mask) - 1;                 // last sub-row that starts at or before lo
+      unsigned long long m = __ballot(Pc > lo && Pc <= lo + 63);          // sub-rows that start inside the step
+      cfv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cc), own0));
+      int dlv = __builtin_amdgcn_readlane(dc, own0);
+      while (m != 0ull) {
+        const int i = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const int Pi = __builtin_amdgcn_readlane(Pc, i);
+        const float cfi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cc), i));
+        const int dli = __builtin_amdgcn_readlane(dc, i);
+        const bool in = pos >= Pi;
+        cfv = in ? cfi : cfv;
+        dlv = in ? dli : dlv;
       }
+      const bool valid = pos < total;
+      cfv = valid ? cfv : 0.f;
+      addr = valid ? pos + dlv : lane;
+      ++t;
     }
-    unsigned b = 0;
-    on = 0;
-    ocf = T(0);
-    if (todo != 0ull) {
-      const int src = __builtin_ctzll(todo);
-      todo &= todo - 1ull;
-      const int n = __builtin_amdgcn_readlane(nc, src) - 64 * h;
-      on = n < 64 ? n : 64;
-      b = (unsigned)__builtin_amdgcn_readlane(bc, src) + 64u * (unsigned)h;
-      ocf = BitsOf<T>::bcast(cc, src);
-      ++live;
-    }
-    oj = midx[b + lane];
-    ov = BINM ? T(1) : mval[b + lane];
+    ocf = cfv;
+    oj = midx4[addr];
+    if constexpr (BINM) ov = f4{1.f, 1.f, 1.f, 1.f};
+    else ov = mval4[addr];
   };
-  auto fold = [&](unsigned short j, T v, int n, T cf) __attribute__((always_inline)) {
-    if constexpr (FIX) {
-      const float x = lane < n ? (float)v : 0.f;
-      atomicAdd(reinterpret_cast<unsigned*>(acc) + j, (unsigned)cvt_rpi((float)cf * x));
-    } else {
-      const int jj = lane < n ? (int)j : dummy;
-      acc[jj] = fma(cf, v, acc[jj]);
-    }
+  auto fold = [&](u2 j, f4 v, float cf) __attribute__((always_inline)) {
+    atomicAdd(acc + (j.x & 0xffffu), (unsigned)cvt_rpi(cf * v.x));
+    atomicAdd(acc + (j.x >> 16), (unsigned)cvt_rpi(cf * v.y));
+    atomicAdd(acc + (j.y & 0xffffu), (unsigned)cvt_rpi(cf * v.z));
+    atomicAdd(acc + (j.y >> 16), (unsigned)cvt_rpi(cf * v.w));
   };
 #pragma unroll
-  for (int i = 0; i < D; ++i) next_piece(sj[i], sv[i], sn[i], scf[i]);
-  while (live > 0 || gcur < ngroups) {
+  for (int i = 0; i < D; ++i) next_step(sj[i], sv[i], sc[i]);
+  while (!done) {
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      fold(sj[i], sv[i], sn[i], scf[i]);
-      live -= sn[i] > 0 ? 1 : 0;
-      next_piece(sj[i], sv[i], sn[i], scf[i]);
+      fold(sj[i], sv[i], sc[i]);
+      next_step(sj[i], sv[i], sc[i]);
     }
   }
+#pragma unroll
+  for (int i = 0; i < D; ++i) fold(sj[i], sv[i], sc[i]);
   T* orow = p.out + r * p.ld + j0;
-  if constexpr (FIX) {
-    const int* iacc = reinterpret_cast<const int*>(acc);
-    for (int j = lane; j < jn; j += 64) orow[j] = (T)((float)iacc[j] * unscale) * p.inv2[j0 + j];
-  } else {
-    for (int j = lane; j < jn; j += 64) orow[j] = acc[j] * p.inv2[j0 + j];
+  const int* iacc = reinterpret_cast<const int*>(acc);
+  for (int j = lane; j < jn; j += 64) orow[j] = ((float)iacc[j] * unscale) * p.inv2[j0 + j];
+}
+
+// ---------------------------------------------------------------- stage 1, wide loads + fixed-point sums (round 3)
+// What the counters of the single-wave kernel say (profiles/r03_stage1_mem_pmc.txt): its 2- and 4-byte-per-lane loads
+// cost the vector L1 ~6 accesses each (TCP_TOTAL_CACHE_ACCESSES ~0.8 per cycle and CU, TA busy 92 %), its LDS
+// read-add-write pairs keep the LDS 64 % busy, and a wave needs ~400 clk per sub-row (readlane -> scalar -> address
+// chains, one LDS round trip per fold).  This kernel removes all three:
+//  * 16 bytes per lane: 16 lanes share a sub-row, lane e takes its entries 4e .. 4e+3 -- ONE global_load_dwordx4
+//    (values) + ONE global_load_dwordx2 (indices) fetch the first 64 entries of FOUR sub-rows;
+//  * sums are 2^k-scaled integers added with ds_add_u32 (half the LDS cycles of the pair, no return value, no wait;
+//    columns of different sub-rows may coincide inside one instruction, which only atomics get right; integer sums do
+//    not depend on any order);
+//  * no per-sub-row scalar work: a wave writes (start, length, coefficient) of its 64 current features to a small LDS
+//    table once per group and every lane reads its sub-row's triple from there (one ds_read per step).
+// Entries past the first 64 of a sub-row (40 % of the sub-rows have some, ~8 on average) are taken afterwards, 4 lanes
+// (16 entries) per sub-row and step, through a list of the features that still have entries left.
+// Workgroup = NW waves = NW rows of L on chunk c; sub-row offsets and exact lengths of the chunk staged in LDS;
+// coefficients precomputed (transfer_coef_kernel); steps run through a ring of D slots, every load unconditional.
+constexpr int WIDE_META = 64 * 12;   // bytes per wave: (start quad, length, coefficient) of 64 features
+constexpr int WIDE_LIST = 64;        // bytes per wave: features with entries left (one byte each)
+template <int D, bool BINM>
+__global__ void __launch_bounds__(1024) transfer_wide_kernel(TransferArgs<float> p, const float* __restrict__ coef,
+                                                             int64_t nrows, int align, int offs_bytes, int lens_bytes,
+                                                             float xmax, const unsigned short* __restrict__ glen) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  int* offs = reinterpret_cast<int*>(smem_raw);
+  unsigned short* lens = reinterpret_cast<unsigned short*>(smem_raw + offs_bytes);
+  unsigned char* ident = smem_raw + offs_bytes + lens_bytes;                 // [64] identity list (first 64 entries: all features)
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int accb = (((p.SC + 4) * 4 + 15) / 16) * 16;   // + the padding column SC (zero entries point at it)
+  unsigned char* mine = smem_raw + offs_bytes + lens_bytes + 64 + (size_t)wave * (size_t)(accb + WIDE_META + WIDE_LIST);
+  unsigned* acc = reinterpret_cast<unsigned*>(mine);
+  unsigned char* metab = mine + accb;                                        // [64][12]
+  unsigned char* list = metab + WIDE_META;                                   // [64]
+  const int c = blockIdx.x % p.nchunks;
+  const int64_t r = (int64_t)(blockIdx.x / p.nchunks) * nw + wave;
+  const ChunkedView<float> M = p.M[0];
+  const CsrView<float> L = p.L[0];
+  {
+    const int* __restrict__ off = M.off + (int64_t)c * M.rows;
+    const unsigned short* __restrict__ gl = glen + (int64_t)c * M.rows;
+    for (int64_t i = threadIdx.x; i <= M.rows; i += blockDim.x) offs[i] = off[i];
+    for (int64_t i = threadIdx.x; i < M.rows; i += blockDim.x) lens[i] = gl[i];
+    if (threadIdx.x < 64) ident[threadIdx.x] = (unsigned char)threadIdx.x;
   }
+  for (int j = lane; j < p.SC; j += 64) acc[j] = 0u;
+  __syncthreads();
+  if (r >= nrows) return;
+  const int64_t gr = p.row_begin + r;
+  const int64_t j0 = (int64_t)c * p.SC;
+  const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
+  const int lb = __builtin_amdgcn_readfirstlane(L.ptr[gr]), le = __builtin_amdgcn_readfirstlane(L.ptr[gr + 1]);
+  float scale, unscale;
+  {
+    float sabs = 0.f;
+    for (int q = lb + lane; q < le; q += 64) sabs += fabsf(coef[q]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sabs += __shfl_xor(sabs, o);
+    int e = 0;
+    (void)frexpf(sabs * xmax, &e);
+    if (!(sabs * xmax > 0.f)) e = 0;
+    e = e < -90 ? -90 : (e > 120 ? 120 : e);
+    scale = ldexpf(1.f, 30 - e);
+    unscale = ldexpf(1.f, e - 30);
+  }
+  const int ngroups = (le - lb + 63) >> 6;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const f4* __restrict__ mval4 = reinterpret_cast<const f4*>(M.val);
+  const u2* __restrict__ midx4 = reinterpret_cast<const u2*>(M.idx);
+  auto raw_load = [&](int g, int& a, float& cf) __attribute__((always_inline)) {
+    const int q = lb + g * 64 + lane;
+    a = 0;
+    cf = 0.f;
+    if (q < le) { a = L.idx[q]; cf = coef[q]; }
+  };
+  // ---- generator state (wave-uniform): group, level (0: entries 0..63, 16 lanes per sub-row; h >= 1: entries
+  // 64 + 16 (h-1) .. +15, 4 lanes per sub-row), step inside the level
+  int gcur = -1, level = 0, st = 0, nst = 0, nlist = 0, qoff = 0;
+  int ncur = 0;            // lane i: length of the sub-row of feature i of the current group
+  int ra;
+  float rc;
+  raw_load(0, ra, rc);
+  bool done = false;
+  auto open_group = [&]() __attribute__((always_inline)) {
+    // the raw (feature, coefficient) pairs of this group are here; those of the next group are requested now
+    ++gcur;
+    const float cf = rc * scale;   // exact: a power of two
+    int b = 0, n = 0;
+    if (cf != 0.f) { b = (offs[ra] * align) >> 2; n = (int)lens[ra]; }
+    raw_load(gcur + 1, ra, rc);
+    ncur = n;
+    unsigned* m = reinterpret_cast<unsigned*>(metab + lane * 12);
+    m[0] = (unsigned)b; m[1] = (unsigned)n; m[2] = __float_as_uint(cf);
+    level = 0;
+    st = 0;
+    qoff = 0;
+    const int cnt = (le - lb - gcur * 64 < 64) ? (le - lb - gcur * 64) : 64;
+    nlist = cnt;
+    nst = (cnt + 3) >> 2;          // four sub-rows per step
+  };
+  auto next_level = [&]() __attribute__((always_inline)) {
+    // features that still have entries: level 1 starts at entry 64, each further level 16 entries on
+    const int covered = 64 + 16 * level;
+    ++level;
+    qoff = covered >> 2;
+    const bool more = ncur > covered;
+    const unsigned long long mk = __ballot(more);
+    nlist = __builtin_popcountll(mk);
+    if (more) list[__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (unsigned char)lane;
+    st = 0;
+    nst = (nlist + 15) >> 4;       // sixteen sub-rows per step
+  };
+  u2 sj[D];
+  f4 sv[D];
+  float sc[D];
+  auto next_step = [&](u2& oj, f4& ov, float& ocf) __attribute__((always_inline)) {
+    if (st >= nst) {
+      if (gcur >= 0 && nlist > 0) next_level();          // (an empty level: nst = 0, handled by the next call)
+      else if (gcur + 1 < ngroups) open_group();
+      else done = true;
+    }
+    float cfv = 0.f;
+    int quad = lane;   // lanes without work add 0 to 64 DIFFERENT columns (64 lanes adding to one LDS word serialise)
+    int rem = 0;       // entries of the sub-row in this lane's quad (the last quad of a sub-row ends in padding)
+    if (st < nst) {
+      const int sh = level == 0 ? 4 : 2;                 // log2(lanes per sub-row)
+      const int pos = (st << (6 - sh)) + (lane >> sh);   // position in the list of features of this level
+      const int e = lane & ((1 << sh) - 1);
+      const unsigned char* lst = level == 0 ? ident : list;
+      const int fi = pos < nlist ? (int)lst[pos] : 0;
+      const unsigned* m = reinterpret_cast<const unsigned*>(metab + fi * 12);
+      const int b = (int)m[0], n = (int)m[1];
+      const float cf = __uint_as_float(m[2]);
+      const int qe = qoff + e;                           // quad of the sub-row this lane takes
+      const bool valid = pos < nlist && 4 * qe < n;
+      cfv = valid ? cf : 0.f;
+      quad = valid ? b + qe : lane;
+      rem = n - 4 * qe;
+      ++st;
+    }
+    ocf = cfv;
+    oj = midx4[quad];
+    // pattern-only operand: the values are not read, so the padding of a sub-row's last quad must be masked here (a
+    // stored padding value is 0, an implied one would be 1 -- added to the padding's column SC)
+    if constexpr (BINM) ov = f4{rem > 0 ? 1.f : 0.f, rem > 1 ? 1.f : 0.f, rem > 2 ? 1.f : 0.f, rem > 3 ? 1.f : 0.f};
+    else ov = mval4[quad];
+  };
+  auto fold = [&](u2 j, f4 v, float cf) __attribute__((always_inline)) {
+    atomicAdd(acc + (j.x & 0xffffu), (unsigned)cvt_rpi(cf * v.x));
+    atomicAdd(acc + (j.x >> 16), (unsigned)cvt_rpi(cf * v.y));
+    atomicAdd(acc + (j.y & 0xffffu), (unsigned)cvt_rpi(cf * v.z));
+    atomicAdd(acc + (j.y >> 16), (unsigned)cvt_rpi(cf * v.w));
+  };
+#pragma unroll
+  for (int i = 0; i < D; ++i) next_step(sj[i], sv[i], sc[i]);
+  while (!done) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      fold(sj[i], sv[i], sc[i]);
+      next_step(sj[i], sv[i], sc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) fold(sj[i], sv[i], sc[i]);
+  float* orow = p.out + r * p.ld + j0;
+  const int* iacc = reinterpret_cast<const int*>(acc);
+  for (int j = lane; j < jn; j += 64) orow[j] = ((float)iacc[j] * unscale) * p.inv2[j0 + j];
+}
+
+// ---------------------------------------------------------------- stage 1, wide loads, static schedule (round 3)
+// transfer_wide_kernel without its step generator (whose scalar control flow cost ~45 instructions and two dependent LDS
+// reads per step: 1.2 ms of the 1.8 ms with loads and atomics removed).  A group of 64 features is ALWAYS 20 steps:
+//   steps  0..15  entries  0..63 of features 4s .. 4s+3        (16 lanes x 4 entries per sub-row)
+//   steps 16..18  entries 64..79 of the features that have them (4 lanes per sub-row, 16 features per step, from list 1)
+//   step  19      entries 80..95 of the features that have them (list 2)
+// so the whole row is one straight-line software pipeline: the loop body is one group, completely unrolled, LDS table
+// reads use immediate offsets, a ring of 4 slots carries the loads across steps and across groups (the table of the
+// next group is written -- into the other of two buffers -- four steps before the current group ends), every load is
+// unconditional and the waits are exact counts.  What the 20 steps cannot hold (a 49th feature longer than 64 entries,
+// a 17th longer than 80, entries past 96; ~1e-4 of the sub-rows at a mean of 62) is added by the owning lane itself,
+// entry by entry, when the table is written.
+constexpr int W2_TBL = 64 * 12;
+constexpr int W2_STEPS = 20;
+constexpr int W2_D = 4;
+template <bool BINM>
+__global__ void __launch_bounds__(1024) transfer_wide2_kernel(TransferArgs<float> p, const float* __restrict__ coef,
+                                                              int64_t nrows, int align, int offs_bytes, int lens_bytes,
+                                                              float xmax, const unsigned short* __restrict__ glen) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  int* offs = reinterpret_cast<int*>(smem_raw);
+  unsigned short* lens = reinterpret_cast<unsigned short*>(smem_raw + offs_bytes);
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int accb = (((p.SC + 4) * 4 + 15) / 16) * 16;   // + the padding column SC (zero entries point at it)
+  const int per_wave = accb + 2 * W2_TBL + 4 * 64;
+  unsigned char* mine = smem_raw + offs_bytes + lens_bytes + (size_t)wave * (size_t)per_wave;
+  unsigned* acc = reinterpret_cast<unsigned*>(mine);
+  unsigned char* tbl0 = mine + accb;                      // two tables [64][12]: (start quad, length, coefficient)
+  unsigned char* lst0 = tbl0 + 2 * W2_TBL;                // two x (list 1 [64], list 2 [64])
+  const int c = blockIdx.x % p.nchunks;
+  const int64_t r = (int64_t)(blockIdx.x / p.nchunks) * nw + wave;
+  const ChunkedView<float> M = p.M[0];
+  const CsrView<float> L = p.L[0];
+  {
+    const int* __restrict__ off = M.off + (int64_t)c * M.rows;
+    const unsigned short* __restrict__ gl = glen + (int64_t)c * M.rows;
+    for (int64_t i = threadIdx.x; i <= M.rows; i += blockDim.x) offs[i] = off[i];
+    for (int64_t i = threadIdx.x; i < M.rows; i += blockDim.x) lens[i] = gl[i];
+  }
+  for (int j = lane; j < p.SC; j += 64) acc[j] = 0u;
+  __syncthreads();
+  if (r >= nrows) return;
+  const int64_t gr = p.row_begin + r;
+  const int64_t j0 = (int64_t)c * p.SC;
+  const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
+  const int lb = __builtin_amdgcn_readfirstlane(L.ptr[gr]), le = __builtin_amdgcn_readfirstlane(L.ptr[gr + 1]);
+  float scale, unscale;
+  {
+    float sabs = 0.f;
+    for (int q = lb + lane; q < le; q += 64) sabs += fabsf(coef[q]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sabs += __shfl_xor(sabs, o);
+    int e = 0;
+    (void)frexpf(sabs * xmax, &e);
+    if (!(sabs * xmax > 0.f)) e = 0;
+    e = e < -90 ? -90 : (e > 120 ? 120 : e);
+    scale = ldexpf(1.f, 30 - e);
+    unscale = ldexpf(1.f, e - 30);
+  }
+  const int ngroups = (le - lb + 63) >> 6;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const f4* __restrict__ mval4 = reinterpret_cast<const f4*>(M.val);
+  const u2* __restrict__ midx4 = reinterpret_cast<const u2*>(M.idx);
+  const unsigned short* __restrict__ midx = M.idx;
+  const float* __restrict__ mval = M.val;
+  const int lastq = le > lb ? le - 1 : lb;   // (an empty row never dereferences: ngroups == 0)
+  // raw (feature, coefficient) pair of this lane in group g; lanes past the end of the row get coefficient 0.
+  // Unconditional loads from a clamped position: no branch, exact wait counts.
+  auto raw_load = [&](int g, int& a, float& cf) __attribute__((always_inline)) {
+    const int q = lb + g * 64 + lane;
+    const int qc = q < le ? q : lastq;
+    a = L.idx[qc];
+    const float x = coef[qc];
+    cf = q < le ? x : 0.f;
+  };
+  // write the table + lists of group g (its raw pair is in (ra, rc)) into buffer g & 1; request the raw pair of g + 1
+  int ra = 0;
+  float rc = 0.f;
+  auto open_group = [&](int g) __attribute__((always_inline)) {
+    unsigned char* tb = tbl0 + (g & 1) * W2_TBL;
+    unsigned char* l1 = lst0 + (g & 1) * 128;
+    unsigned char* l2 = l1 + 64;
+    const float cf = (g < ngroups) ? rc * scale : 0.f;   // exact: a power of two
+    int b = 0, n = 0;
+    if (cf != 0.f) { b = (offs[ra] * align) >> 2; n = (int)lens[ra]; }
+    raw_load(g + 1, ra, rc);                            // (clamped past the end of the row: always safe, never a branch)
+    unsigned* m = reinterpret_cast<unsigned*>(tb + lane * 12);
+    m[0] = (unsigned)b; m[1] = (unsigned)n; m[2] = __float_as_uint(cf);
+    const unsigned long long m1 = __ballot(n > 64), m2 = __ballot(n > 80);
+    const int r1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+    const int r2 = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u));
+    l1[lane] = 255; l2[lane] = 255;                      // 255 = no feature at this list position
+    if (n > 64) l1[r1] = (unsigned char)lane;
+    if (n > 80) l2[r2] = (unsigned char)lane;
+    // the rare rest: entries the 20 steps do not reach, added by the owning lane
+    int cov = 64;
+    if (n > 64 && r1 < 48) cov = 80;
+    if (cov == 80 && n > 80 && r2 < 16) cov = 96;
+    if (__ballot(n > cov) != 0ull) {
+      for (int x = cov; x < n; ++x) {
+        const int at = 4 * b + x;
+        atomicAdd(acc + midx[at], (unsigned)cvt_rpi(cf * (BINM ? 1.f : mval[at])));
+      }
+    }
+  };
+  // ---- the ring
+  u2 sj[W2_D];
+  f4 sv[W2_D];
+  float sc[W2_D];
+  auto fetch = [&](int quad, float cfv, int rem, u2& oj, f4& ov, float& ocf) __attribute__((always_inline)) {
+    ocf = cfv;
+    oj = midx4[quad];
+    // pattern-only operand: the values are not read, so the padding of a sub-row's last quad is masked here
+    if constexpr (BINM) ov = f4{rem > 0 ? 1.f : 0.f, rem > 1 ? 1.f : 0.f, rem > 2 ? 1.f : 0.f, rem > 3 ? 1.f : 0.f};
+    else ov = mval4[quad];
+  };
+  // step s (compile-time after unrolling) of the group whose table sits in buffer `par`
+  auto gen = [&](int s, int par, u2& oj, f4& ov, float& ocf) __attribute__((always_inline)) {
+    const unsigned char* tb = tbl0 + par * W2_TBL;
+    int fi, e, qoff;
+    bool have = true;
+    if (s < 16) {
+      fi = 4 * s + (lane >> 4);
+      e = lane & 15;
+      qoff = 0;
+    } else {
+      const unsigned char* lst = lst0 + par * 128 + (s < 19 ? 0 : 64);
+      const int pos = (s < 19 ? 16 * (s - 16) : 0) + (lane >> 2);
+      fi = (int)lst[pos];
+      have = fi != 255;
+      fi = have ? fi : 0;
+      e = lane & 3;
+      qoff = s < 19 ? 16 : 20;
+    }
+    const unsigned* m = reinterpret_cast<const unsigned*>(tb + fi * 12);
+    const int b = (int)m[0], n = (int)m[1];
+    const float cf = __uint_as_float(m[2]);
+    const int qe = qoff + e;
+    const bool valid = have && 4 * qe < n;
+    // lanes without work add 0 to 64 DIFFERENT columns (many lanes adding to one LDS word serialise)
+    fetch(valid ? b + qe : lane, valid ? cf : 0.f, n - 4 * qe, oj, ov, ocf);
+  };
+  auto fold = [&](u2 j, f4 v, float cf) __attribute__((always_inline)) {
+    atomicAdd(acc + (j.x & 0xffffu), (unsigned)cvt_rpi(cf * v.x));
+    atomicAdd(acc + (j.x >> 16), (unsigned)cvt_rpi(cf * v.y));
+    atomicAdd(acc + (j.y & 0xffffu), (unsigned)cvt_rpi(cf * v.z));
+    atomicAdd(acc + (j.y >> 16), (unsigned)cvt_rpi(cf * v.w));
+  };
+  if (ngroups > 0) {
+    raw_load(0, ra, rc);
+    open_group(0);
+#pragma unroll
+    for (int i = 0; i < W2_D; ++i) gen(i, 0, sj[i], sv[i], sc[i]);
+    for (int g = 0; g < ngroups; ++g) {
+      const int par = g & 1;
+#pragma unroll
+      for (int s = 0; s < W2_STEPS; ++s) {
+        if (s == W2_STEPS - W2_D) open_group(g + 1);     // (past the last group: an empty table, all steps idle)
+        fold(sj[s % W2_D], sv[s % W2_D], sc[s % W2_D]);
+        if (s + W2_D < W2_STEPS) gen(s + W2_D, par, sj[s % W2_D], sv[s % W2_D], sc[s % W2_D]);
+        else gen(s + W2_D - W2_STEPS, par ^ 1, sj[s % W2_D], sv[s % W2_D], sc[s % W2_D]);
+      }
+    }
+    // the ring now holds the first steps of the (empty) group past the end: nothing left to add
+  }
+  float* orow = p.out + r * p.ld + j0;
+  const int* iacc = reinterpret_cast<const int*>(acc);
+  for (int j = lane; j < jn; j += 64) orow[j] = ((float)iacc[j] * unscale) * p.inv2[j0 + j];
 }
 
 // waves per workgroup of the block kernel that fit next to the offsets: 0 = does not fit (fall back)
@@ -742,61 +1079,67 @@ int launch_transfer_block(const DevCsr<T>& L, const T* inv1, const DevChunked<T>
   constexpr bool CANFIX = std::is_same<T, float>::value;
   const bool fx = CANFIX && fixed;
   if (fx) path_add("fixed_point");
-  // (U, K): sub-rows per register set, sets in the ring (K = 0: the loop per 64-feature group)
-  int pu = 8, pk = 3;
-  if (const char* e = getenv("SS_TRANSFER_PIPE")) {
-    int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2) { pu = a; pk = b; }
-  }
-  int ring = 16;
-  if (const char* e = getenv("SS_TRANSFER_RING")) ring = atoi(e);
-#define SS_TR_LAUNCH(D, BINM, FIX)                                                                                    \
+  if constexpr (std::is_same<T, float>::value) {
+    // the fixed-point kernels with 16 bytes per lane: they walk exact sub-row lengths (operand cut with align 32)
+    auto envi = [](const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; };
+    const int wide2 = envi("SS_TRANSFER_WIDE2"), wide = envi("SS_TRANSFER_WIDE"), qflat = envi("SS_TRANSFER_QFLAT");
+    if ((wide2 > 0 || wide > 0 || qflat > 0) && fixed && Mt.align == 32 && Mt.len_ok) {
+      const int64_t lens_bytes = ((Mt.rows * 2 + 15) / 16) * 16;
+      const int64_t accb = ((((int64_t)p.SC + 4) * 4 + 15) / 16) * 16;
+      const int64_t per_wave = wide2 > 0 ? accb + 2 * W2_TBL + 4 * 64
+                               : wide > 0 ? accb + WIDE_META + WIDE_LIST : (int64_t)(p.SC + 64) * 4;
+      const int64_t fixed_bytes = (int64_t)offs_bytes + lens_bytes + (wide > 0 && wide2 == 0 ? 64 : 0);
+      int64_t nwf = ((int64_t)ctx().lds_per_block - fixed_bytes) / per_wave;
+      if (nwf > 16) nwf = 16;
+      if (const int v = envi("SS_TRANSFER_NW"); v >= 1 && v < nwf) nwf = v;
+      if (nwf >= 8) {
+        const int64_t fgrid = ceil_div(nrows, nwf) * p.nchunks;
+        const size_t flds = (size_t)fixed_bytes + (size_t)nwf * (size_t)per_wave;
+        const unsigned short* glen = Mt.len.p;
+#define SS_TX_LAUNCH(KERNEL)                                                                                          \
   do {                                                                                                                \
     static std::atomic<bool> attr_done{false};                                                                        \
     if (!attr_done) {                                                                                                 \
-      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_ring_kernel<T, D, BINM, FIX>),               \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                 160 * 1024));                                                                        \
       attr_done = true;                                                                                               \
     }                                                                                                                 \
-    hipLaunchKernelGGL((transfer_ring_kernel<T, D, BINM, FIX>), dim3((unsigned)grid), dim3(64 * nw), lds,             \
-                       ctx().stream, p, (const T*)coef, nrows, Mt.align, offs_bytes, xmax);                           \
+    hipLaunchKernelGGL(KERNEL, dim3((unsigned)fgrid), dim3(64 * (int)nwf), flds, ctx().stream, p, (const float*)coef,  \
+                       nrows, Mt.align, offs_bytes, (int)lens_bytes, xmax, glen);                                     \
   } while (0)
-#define SS_TR_BIN(D, FIX) do { if (Mt.binary) SS_TR_LAUNCH(D, true, FIX); else SS_TR_LAUNCH(D, false, FIX); } while (0)
-#define SS_TR_FIX(D) do { if (fx) SS_TR_BIN(D, CANFIX); else SS_TR_BIN(D, false); } while (0)
-  if (ring > 0) {
-    path_add("ring");
-    if (ring == 8) SS_TR_FIX(8);
-    else if (ring == 12) SS_TR_FIX(12);
-    else if (ring == 24) SS_TR_FIX(24);
-    else if (ring == 32) SS_TR_FIX(32);
-    else SS_TR_FIX(16);
-    SS_LAUNCH_CHECK();
-    return SS_OK;
+        if (wide2 > 0) {
+          path_add("wide2");
+          if (Mt.binary) SS_TX_LAUNCH((transfer_wide2_kernel<true>)); else SS_TX_LAUNCH((transfer_wide2_kernel<false>));
+        } else if (wide > 0) {
+          path_add("wide");
+          if (wide == 2) { if (Mt.binary) SS_TX_LAUNCH((transfer_wide_kernel<2, true>)); else SS_TX_LAUNCH((transfer_wide_kernel<2, false>)); }
+          else { if (Mt.binary) SS_TX_LAUNCH((transfer_wide_kernel<4, true>)); else SS_TX_LAUNCH((transfer_wide_kernel<4, false>)); }
+        } else {
+          path_add("qflat");
+          if (Mt.binary) SS_TX_LAUNCH((transfer_qflat_kernel<float, 4, true>)); else SS_TX_LAUNCH((transfer_qflat_kernel<float, 4, false>));
+        }
+#undef SS_TX_LAUNCH
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+      }
+    }
   }
-#undef SS_TR_FIX
-#undef SS_TR_BIN
-#undef SS_TR_LAUNCH
-#define SS_TB_LAUNCH(U, BINM, FIX, K)                                                                                 \
+  const int pu = transfer_u() == 4 ? 4 : 8;
+#define SS_TB_LAUNCH(U, BINM, FIX)                                                                                    \
   do {                                                                                                                \
     static std::atomic<bool> attr_done{false};                                                                        \
     if (!attr_done) {                                                                                                 \
-      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_block_kernel<T, U, BINM, FIX, K>),           \
+      SS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transfer_block_kernel<T, U, BINM, FIX>),              \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
       attr_done = true;                                                                                               \
     }                                                                                                                 \
-    hipLaunchKernelGGL((transfer_block_kernel<T, U, BINM, FIX, K>), dim3((unsigned)grid), dim3(64 * nw), lds,         \
+    hipLaunchKernelGGL((transfer_block_kernel<T, U, BINM, FIX>), dim3((unsigned)grid), dim3(64 * nw), lds,            \
                        ctx().stream, p, (const T*)coef, nrows, Mt.align, offs_bytes, xmax);                           \
   } while (0)
-#define SS_TB_BIN(U, FIX, K) do { if (Mt.binary) SS_TB_LAUNCH(U, true, FIX, K); else SS_TB_LAUNCH(U, false, FIX, K); } while (0)
-#define SS_TB_FIX(U, K) do { if (fx) SS_TB_BIN(U, CANFIX, K); else SS_TB_BIN(U, false, K); } while (0)
-  if (pu == 8 && pk == 0) SS_TB_FIX(8, 0);
-  else if (pu == 4 && pk == 0) SS_TB_FIX(4, 0);
-  else if (pu == 8 && pk == 2) SS_TB_FIX(8, 2);
-  else if (pu == 4 && pk == 4) SS_TB_FIX(4, 4);
-  else if (pu == 4 && pk == 6) SS_TB_FIX(4, 6);
-  else if (pu == 8 && pk == 4) SS_TB_FIX(8, 4);
-  else if (pu == 16 && pk == 2) SS_TB_FIX(16, 2);
-  else SS_TB_FIX(8, 3);
+#define SS_TB_BIN(U, FIX) do { if (Mt.binary) SS_TB_LAUNCH(U, true, FIX); else SS_TB_LAUNCH(U, false, FIX); } while (0)
+#define SS_TB_FIX(U) do { if (fx) SS_TB_BIN(U, CANFIX); else SS_TB_BIN(U, false); } while (0)
+  if (pu == 4) SS_TB_FIX(4);
+  else SS_TB_FIX(8);
 #undef SS_TB_FIX
 #undef SS_TB_BIN
 #undef SS_TB_LAUNCH
@@ -821,6 +1164,23 @@ static int launch_transfer_variant(const TransferArgs<T>& p, unsigned grid, size
     else { if (dual) SS_TRANSFER_LAUNCH(U, false, true); else SS_TRANSFER_LAUNCH(U, false, false); }    \
   } while (0)
   if constexpr (std::is_same<T, float>::value && !LOO) {
+    const char* eb = getenv("SS_TRANSFER_LD");
+    if (eb && atoi(eb) == 1 && !dual) {
+      path_add("buffer_loads");
+      const bool fx = getenv("SS_TRANSFER_FIX1") && atoi(getenv("SS_TRANSFER_FIX1")) == 1 && p.nterms == 1 && !p.accumulate;
+      if (fx) path_add("fixed_point");
+#define SS_TL(U, BINM, FX) hipLaunchKernelGGL((transfer_kernel<T, LOO, U, BINM, false, FX, true>), dim3(grid), dim3(TRANSFER_THREADS), lds, ctx().stream, p)
+      if (transfer_u() == 4) {
+        if (binm) { if (fx) SS_TL(4, true, true); else SS_TL(4, true, false); }
+        else { if (fx) SS_TL(4, false, true); else SS_TL(4, false, false); }
+      } else {
+        if (binm) { if (fx) SS_TL(8, true, true); else SS_TL(8, true, false); }
+        else { if (fx) SS_TL(8, false, true); else SS_TL(8, false, false); }
+      }
+#undef SS_TL
+      SS_LAUNCH_CHECK();
+      return SS_OK;
+    }
     const char* e = getenv("SS_TRANSFER_FIX1");
     if (e && atoi(e) == 1 && p.nterms == 1 && !dual && !p.accumulate) {
       path_add("fixed_point");

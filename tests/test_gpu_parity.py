@@ -894,3 +894,41 @@ def test_tutorial_example_runs_end_to_end_on_the_device():
     out = mod.main(0.9)
     for weighted in (True, False):
         assert out[weighted]["AuROC"] > 0.9 and out[weighted]["accuracy_of_predicted"] > 0.9   # iris is easy
+
+
+# ----------------------------------------------------------------------------- stage-1 variants of round 3 (opt-in kernels)
+@pytest.mark.parametrize("variant", [
+    {"SS_TRANSFER_V": "2", "SS_TRANSFER_FIX": "0"},                    # query-block workgroups, plain read-add-write
+    {"SS_TRANSFER_V": "2"},                                            # ... with fixed-point ds_add_u32 sums
+    {"SS_TRANSFER_V": "2", "SS_TRANSFER_QFLAT": "4"},                  # flat stream of quads
+    {"SS_TRANSFER_V": "2", "SS_TRANSFER_WIDE": "4"},                   # 16 bytes per lane, step generator
+    {"SS_TRANSFER_V": "2", "SS_TRANSFER_WIDE2": "1"},                  # 16 bytes per lane, static 20-step schedule
+    {"SS_TRANSFER_V": "1", "SS_TRANSFER_FIX1": "1"},                   # single-wave kernel with fixed-point sums
+    {"SS_TRANSFER_V": "1", "SS_TRANSFER_LD": "1"},                     # single-wave kernel with buffer loads
+])
+@pytest.mark.parametrize("chunk", [None, "3000"])
+def test_stage1_variants_match_the_oracle(variant, chunk, monkeypatch):
+    """The measured-but-not-default stage-1 kernels against the CPU oracle: default chunking
+    (short sub-rows) and one 3000-column chunk (150-entry sub-rows: second and third levels of the wide kernels, their
+    per-lane rest path past 96 entries).  Zero-degree features, an empty query row, weighted and unweighted features.
+    Fixed-point sums: error bound n_terms * 2^-30 * (sum |coefficients|) * max |value| per score."""
+    for k, v in variant.items():
+        monkeypatch.setenv(k, v)
+    if chunk:
+        monkeypatch.setenv("SS_TRANSFER_CHUNK", chunk)
+    for weighted in (True, False):
+        Xq, Xs, Ys = O.synth_bipartite(257, 3000, 3000, 200, 0.05, 0.03, seed=11, weighted=weighted, dtype=np.float32)
+        Xq = Xq.tolil(); Xq[5, :] = 0; Xq = Xq.tocsr()                     # a query without features
+        Xs = Xs.tolil(); Xs[:, 17] = 0; Xs[:, 18] = 0; Xs = Xs.tocsr()     # features nobody has (degree 0)
+        g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+        got = g.predict("query")
+        path = ss.path_last()
+        if variant.get("SS_TRANSFER_V") == "2":
+            assert "transfer_block" in path, path
+            for tag, key in (("qflat", "SS_TRANSFER_QFLAT"), ("wide", "SS_TRANSFER_WIDE"), ("wide2", "SS_TRANSFER_WIDE2")):
+                if key in variant:
+                    assert tag in path, path
+        want = O.predict_factored(Xq.astype(np.float64), Xs.astype(np.float64), Ys.astype(np.float64))
+        assert_close(got, want, np.float32)
+        assert (got[5] == 0).all()
+        g.close()

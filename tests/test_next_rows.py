@@ -1,5 +1,5 @@
 """"Next" rows of SURVEY 8(f): `save` (byte-for-byte against the reference's fixtures test/data/save1-4,
-test/runtests.jl:185-203) and `split` (group sizes / fold rule; the reference's own test is skipped)."""
+test/runtests.jl:185-203) and `split` (the reference's expected grouping, reproduced through Julia's MersenneTwister + shuffle! stream)."""
 import os
 
 import numpy as np
@@ -26,6 +26,31 @@ def test_save_matches_reference_fixtures(tmp_path):
     ss.save(str(p), 3, yh, yy); ss.save(str(p), 4, yh, yy)
     assert p.read_text().splitlines()[1] == '3\t"q1"\t"t2"\t0.5\t1.0'
     assert p.read_text().splitlines()[5] == '4\t"q1"\t"t3"\t-99.0\t0.0'
+
+
+def test_split_equals_the_reference_grouping(kats):
+    """test/runtests.jl:30-34: the reference's expected grouping for seed 1, k 5 (its @test is skip=true, the vector is
+    what SimSpread.split returned when the test was written) -- reproduced exactly: Julia's MersenneTwister(seed) +
+    shuffle! stream (simspread.jl_amd/julia_rng.py) and the fold rule mod(i, k) + 1."""
+    kat = kats["split"]
+    y = ss.NamedMatrix(np.zeros((10, 5)), kat["sources"], kat["targets"])
+    assert ss.split(y, kat["k"], seed=kat["seed"]) == kat["groups"]
+
+
+def test_julia_mersenne_twister_stream():
+    """Known answers of Julia's MersenneTwister (dSFMT-19937 seeded by init_by_array): rand(MersenneTwister(1)) =
+    0.23603334566204692 (the value every Julia 1.x prints), the stream is deterministic, seeds differ, 64-bit seeds are
+    split into two 32-bit limbs."""
+    from simspread_jl_amd.julia_rng import MersenneTwister, shuffle
+    r = MersenneTwister(1)
+    assert r.rand() == 0.23603334566204692
+    assert [MersenneTwister(1).rand() for _ in range(2)] == [0.23603334566204692] * 2
+    assert MersenneTwister(2).rand() != MersenneTwister(1).rand()
+    assert MersenneTwister((1 << 32) + 1).rand() != MersenneTwister(1).rand()
+    xs = [r.rand() for _ in range(2000)]          # crosses several 382-value refills
+    assert all(0.0 <= x < 1.0 for x in xs) and abs(sum(xs) / len(xs) - 0.5) < 0.03
+    assert shuffle([], 1) == [] and shuffle(["a"], 1) == ["a"]
+    assert sorted(shuffle(range(1000), 3)) == list(range(1000))
 
 
 def test_split_fold_rule():

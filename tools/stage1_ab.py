@@ -17,7 +17,7 @@ import simspread_jl_amd as ss
 from bench import synth_c2
 
 KEYS = ("SS_CHUNK_SCHED", "SS_TRANSFER_DUAL", "SS_TRANSFER_CHUNK", "SS_TRANSFER_U", "SS_TRANSFER_QB", "SS_TRANSFER_V",
-        "SS_TRANSFER_ALIGN", "SS_TRANSFER_NW", "SS_TRANSFER_X", "SS_TRANSFER_FIX", "SS_TRANSFER_FIX1", "SS_TRANSFER_PIPE", "SS_TRANSFER_RING")
+        "SS_TRANSFER_ALIGN", "SS_TRANSFER_NW", "SS_TRANSFER_X", "SS_TRANSFER_FIX", "SS_TRANSFER_FIX1", "SS_TRANSFER_PIPE", "SS_TRANSFER_RING", "SS_TRANSFER_FLAT", "SS_TRANSFER_LD", "SS_TRANSFER_QFLAT", "SS_TRANSFER_WIDE", "SS_TRANSFER_DBG", "SS_TRANSFER_WIDE2")
 
 
 def main():
