@@ -128,6 +128,7 @@ struct TransferArgs {
   int64_t ld;
   int accumulate;  // add to what `out` already holds (dense regime: the feature path came from the GEMM)
   float xmax;      // FIX: largest |value| of the Mt operand
+  int small_weighted;  // host only: weighted operand of at most 32 MiB (picks the default batch size)
 };
 
 // One single-wave workgroup per (row r of L, column chunk c of T); c = blockIdx % nchunks so that,
@@ -429,9 +430,12 @@ static bool transfer_dual() {
   return e ? atoi(e) != 0 : false;
 }
 
-static int transfer_u() {
+// sub-rows in flight per wave.  Default 8; 4 (55 instead of 90 registers: 30 instead of 20 single-wave workgroups per CU)
+// where it measured faster: weighted operands that stay in L2 (C2: 1.46 vs 1.51 ms; pattern-only operands 1.24 vs
+// 1.19 ms and the 600 MB operand of C3 5.1 vs 4.6 ms go the other way).  SS_TRANSFER_U overrides.
+static int transfer_u(bool small_weighted = false) {
   const char* e = getenv("SS_TRANSFER_U");
-  const int u = e ? atoi(e) : TRANSFER_U;
+  const int u = e ? atoi(e) : (small_weighted ? 4 : TRANSFER_U);
   return (u == 4 || u == 16) ? u : 8;
 }
 
@@ -1170,7 +1174,7 @@ static int launch_transfer_variant(const TransferArgs<T>& p, unsigned grid, size
       const bool fx = getenv("SS_TRANSFER_FIX1") && atoi(getenv("SS_TRANSFER_FIX1")) == 1 && p.nterms == 1 && !p.accumulate;
       if (fx) path_add("fixed_point");
 #define SS_TL(U, BINM, FX) hipLaunchKernelGGL((transfer_kernel<T, LOO, U, BINM, false, FX, true>), dim3(grid), dim3(TRANSFER_THREADS), lds, ctx().stream, p)
-      if (transfer_u() == 4) {
+      if (transfer_u(p.small_weighted != 0 && !LOO) == 4) {
         if (binm) { if (fx) SS_TL(4, true, true); else SS_TL(4, true, false); }
         else { if (fx) SS_TL(4, false, true); else SS_TL(4, false, false); }
       } else {
@@ -1184,7 +1188,7 @@ static int launch_transfer_variant(const TransferArgs<T>& p, unsigned grid, size
     const char* e = getenv("SS_TRANSFER_FIX1");
     if (e && atoi(e) == 1 && p.nterms == 1 && !dual && !p.accumulate) {
       path_add("fixed_point");
-      if (transfer_u() == 4) {
+      if (transfer_u(p.small_weighted != 0 && !LOO) == 4) {
         if (binm) hipLaunchKernelGGL((transfer_kernel<T, LOO, 4, true, false, true>), dim3(grid), dim3(TRANSFER_THREADS), lds, ctx().stream, p);
         else hipLaunchKernelGGL((transfer_kernel<T, LOO, 4, false, false, true>), dim3(grid), dim3(TRANSFER_THREADS), lds, ctx().stream, p);
       } else {
@@ -1195,7 +1199,7 @@ static int launch_transfer_variant(const TransferArgs<T>& p, unsigned grid, size
       return SS_OK;
     }
   }
-  switch (transfer_u()) {
+  switch (transfer_u(p.small_weighted != 0 && !LOO)) {
     case 4: SS_TRANSFER_U(4); break;
     case 16: SS_TRANSFER_U(16); break;
     default: SS_TRANSFER_U(8); break;
@@ -1230,6 +1234,15 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
   p.ld = ld;
   p.accumulate = accumulate ? 1 : 0;
   p.xmax = 1.0f;
+  {
+    int64_t bytes = 0;
+    bool weighted = false;
+    for (int t = 0; t < nterms; ++t) {
+      bytes += Mt[t]->stored * (int64_t)(2 + sizeof(T));
+      weighted = weighted || !Mt[t]->binary;
+    }
+    p.small_weighted = (weighted && bytes <= (32LL << 20)) ? 1 : 0;
+  }
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
   bool binm = true;
