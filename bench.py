@@ -650,9 +650,12 @@ def main():
             "traffic": s1_pmc["hbm_bytes_per_launch"] if s1_pmc else None, "traffic_source": s1_src,
             "avg_launch_ms": round(transfer_ms, 4), "algorithmic_bytes": s1_bytes,
             "flops": s1_flops, "frac_fp32_fma": round(s1_flops / (transfer_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-            "limiter": "not HBM: every query re-reads 5 % of X' as ~62-entry sub-rows from its XCD's L2 (95 % hits); the L2 -> L1 "
-                       "path moves 64 B per request and clock and channel (measured ceiling 18.7 TB/s for this access pattern, "
-                       "tools/subrow_fetch_bench.hip) and the sub-row sectors add up to ~18.5 GB per launch (DESIGN.md 4.1)",
+            "limiter": "not HBM: two on-chip units, both measured (profiles/r03_stage1_mem_pmc.txt, DESIGN.md 4.1): (1) the vector memory "
+                       "path of a CU moves ~28-32 B/clk whatever the load width (TA busy 92 %, TCP_TOTAL_CACHE_ACCESSES 0.78 per clk): every "
+                       "query re-reads 5 % of X' as ~62-entry sub-rows from its XCD's L2 (95 % hits), ~18.5 GB per launch against "
+                       "~17 TB/s for the chip; (2) the LDS scatter: one read-add-write pair per 64 entries at ~3 LDS cycles per 32-lane "
+                       "group (the fullest of 32 banks holds ~6 of a sub-row's 62 columns), LDS 64 % busy.  Seven rebuilt variants of "
+                       "round 3 (LDS-resident offsets, 16-byte loads, fixed-point ds_add_u32 sums, flat streams) all land at 1.8-3 ms",
             "l2_request_bytes": s1_pmc["l2_request_bytes_per_launch"] if s1_pmc else None,
             "frac_l2_sector_ceiling": (round(s1_pmc["l2_request_bytes_per_launch"] / (transfer_ms * 1e-3) / 1e9 / 18700.0, 4)
                                        if s1_pmc else None),

@@ -133,6 +133,41 @@ def test_featurize_construct_predict_chain_vs_literal(weighted):
     assert_close(got_mix.array, O.predict(A, B, oy.sub(rows, cols)).array, np.float64)
 
 
+def test_predict_general_path_and_clean_outside_the_targets(kats):
+    """The branches julia/SimSpreadDevice.jl takes when the block asked for is NOT [queries|sources] x targets -- the
+    same ones core.py takes, pinned here against the literal oracle so that a maintainer can diff behaviours (no Julia
+    runs here): (1) predict((A,B), y) with feature ROWS or source COLUMNS falls back to the general A*(W*W) path
+    (_node_groups cannot place the names); (2) clean!(yhat, A, y) with column names that are not targets uses the
+    degree of those rows of the dense A (src/core.jl:479 looks at A[name, :] whatever the name is)."""
+    c = kats["construct"]
+    X, y = ss.NamedMatrix(c["X"], c["X_rows"], c["X_cols"]), ss.NamedMatrix(c["y"], c["y_rows"], c["y_cols"])
+    oX, oy = O.Named(c["X"], c["X_rows"], c["X_cols"]), O.Named(c["y"], c["y_rows"], c["y_cols"])
+    A, B = ss.construct(y, X, c["queries"])
+    oA, oB = O.construct_queries(oy, oX, c["queries"])
+    nodes = c["node_order"]
+    feats = [n for n in nodes if n in set(X.cols) and n in set(A.names(1))]
+    srcs = [n for n in y.rows if n not in c["queries"]]
+    # (1) rows = features, columns = sources: nothing of it is a query/source x target block
+    blk = ss.NamedMatrix(np.zeros((len(feats), len(srcs))), feats, srcs)
+    oblk = O.Named(np.zeros((len(feats), len(srcs))), feats, srcs)
+    got = ss.predict((A, B), blk)
+    want = O.predict(oA, oB, oblk)
+    assert got.names(1) == feats and got.names(2) == srcs
+    np.testing.assert_allclose(got.array, want.array, rtol=1e-12, atol=1e-15)
+    # mixed: one query row, one feature row (the feature row forces the general path for the whole call)
+    rows = [c["queries"][0], feats[0]]
+    blk2 = ss.NamedMatrix(np.zeros((2, len(y.cols))), rows, list(y.cols))
+    got2 = ss.predict(A, B, blk2)
+    want2 = O.predict(oA, oB, O.Named(np.zeros((2, len(y.cols))), rows, list(y.cols)))
+    np.testing.assert_allclose(got2.array, want2.array, rtol=1e-12, atol=1e-15)
+    # (2) clean! with non-target column names: the degree of those rows of A decides
+    yh = ss.NamedMatrix(np.ones((1, len(feats))), [c["queries"][0]], feats)
+    oyh = O.Named(np.ones((1, len(feats))), [c["queries"][0]], feats)
+    ss.clean(yh, A, yh)
+    O.clean(oyh, oA, oyh)
+    np.testing.assert_array_equal(yh.array, oyh.array)
+
+
 # ----------------------------------------------------------------------------- engine parity on seeded synthetic graphs
 CASES = [
     # nq, ns, nf, nt, dx, dy, weighted

@@ -8,9 +8,13 @@ set -u
 TAG=${1:-r03}
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-P=gpurun_out/prof_${TAG}
-mkdir -p $P
-LOG=$P/progress.txt
+# raw rocprofv3 output (kernel traces: tens of MB) stays in /tmp on the box; summaries, logs and the small JSON files go to
+# gpurun_out/prof_<tag>/ (gpurun copies back at most 64 MiB)
+P=/tmp/prof_${TAG}
+S=$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}
+rm -rf $P ${P}_*
+mkdir -p $P $S
+LOG=$S/progress.txt
 : > $LOG
 SHA=$(python3 -c "import simspread_jl_amd as s; print(s._lib.source_hash())")
 echo "source_sha $SHA" | tee -a $LOG
@@ -22,7 +26,9 @@ pass() {   # pass <dir> <counters or ""> -- program args...
   else
     timeout -k 5 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -- "$@" > $d.log 2>&1
   fi
-  echo "   rc $?" >> $LOG
+  local rc=$?
+  echo "   rc $rc" >> $LOG
+  if [ $rc -ne 0 ]; then tail -5 $d.log >> $LOG; fi
 }
 BENCH="python3 bench.py --no-sweep --no-cpu-baseline --no-c3 --no-c5"
 # ---- C2
@@ -35,8 +41,8 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   name=$(echo $grp | cut -d' ' -f1)
   pass ${P}_c2/pmc_$name "$grp" $BENCH --steps 5 --warmup 2
 done
-python3 tools/prof_summary.py ${P}_c2 > ${P}_c2/summary.txt 2>&1
-python3 tools/pmc_to_json.py ${P}_c2 $TAG > /dev/null 2>&1
+python3 tools/prof_summary.py ${P}_c2 > $S/c2_summary.txt 2>&1; cp ${P}_c2/trace/*/*kernel_stats.csv $S/c2_kernel_stats.csv 2>/dev/null
+python3 tools/pmc_to_json.py ${P}_c2 $TAG > $S/pmc_to_json.log 2>&1
 # ---- C3 block
 mkdir -p ${P}_c3
 export CHECK=0
@@ -45,9 +51,9 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_
   name=$(echo $grp | cut -d' ' -f1)
   pass ${P}_c3/pmc_$name "$grp" python3 tools/c3_loo.py
 done
-python3 tools/prof_summary.py ${P}_c3 > ${P}_c3/summary.txt 2>&1
+python3 tools/prof_summary.py ${P}_c3 > $S/c3_summary.txt 2>&1
 echo "$(date +%T) c3 full loo" >> $LOG
-timeout -k 5 300 python3 tools/c3_full_loo.py > ${P}_c3/full_loo.json 2> ${P}_c3/full_loo.err
+timeout -k 5 300 python3 tools/c3_full_loo.py > $S/c3_full_loo.json 2> $S/c3_full_loo.err
 # ---- C5 block
 mkdir -p ${P}_c5
 pass ${P}_c5/trace "" python3 tools/c5_powerlaw.py
@@ -55,7 +61,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_
   name=$(echo $grp | cut -d' ' -f1)
   pass ${P}_c5/pmc_$name "$grp" python3 tools/c5_powerlaw.py
 done
-python3 tools/prof_summary.py ${P}_c5 > ${P}_c5/summary.txt 2>&1
+python3 tools/prof_summary.py ${P}_c5 > $S/c5_summary.txt 2>&1
 # ---- C4: bf16 ring kernel at 50k, fp64 kernel at 20k (one alpha, both weightings)
 for cfg in "50000 f32 c4ring" "20000 f64 c4f64"; do
   set -- $cfg
@@ -67,7 +73,8 @@ for cfg in "50000 f32 c4ring" "20000 f64 c4f64"; do
     name=$(echo $grp | cut -d' ' -f1)
     pass ${P}_$3/pmc_$name "$grp" python3 tools/c4_dense.py
   done
-  timeout -k 5 300 python3 tools/c4_dense.py > ${P}_$3/timings.jsonl 2> ${P}_$3/timings.err
+  timeout -k 5 300 python3 tools/c4_dense.py > $S/$3_timings.jsonl 2> $S/$3_timings.err
+  python3 tools/prof_summary_c4.py ${P}_$3 > $S/$3_summary.txt 2>&1
 done
 unset N DTYPE ALPHAS
 # ---- narrow / mid sweep
@@ -79,5 +86,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
   name=$(echo $grp | cut -d' ' -f1)
   pass ${P}_sweep/pmc_$name "$grp" python3 tools/sweep.py
 done
-python3 tools/prof_summary.py ${P}_sweep > ${P}_sweep/summary.txt 2>&1
+python3 tools/prof_summary.py ${P}_sweep > $S/sweep_summary.txt 2>&1; cp ${P}_sweep/trace/*/*kernel_stats.csv $S/sweep_kernel_stats.csv 2>/dev/null; tail -c 6000 ${P}_sweep/trace.log > $S/sweep_trace_tail.log
+echo "source_sha $SHA" > $S/source_sha.txt
 echo "$(date +%T) done" >> $LOG
