@@ -42,6 +42,15 @@ def test_julia_mersenne_twister_stream():
     0.23603334566204692 (the value every Julia 1.x prints), the stream is deterministic, seeds differ, 64-bit seeds are
     split into two 32-bit limbs."""
     from simspread_jl_amd.julia_rng import MersenneTwister, shuffle
+    # streams Julia 1.x prints for rand(MersenneTwister(seed), 3) (seeds 0 and 1234 are the ones Julia's own
+    # documentation and issue tracker quote; none of this comes from the reference repository, whose only vector for this
+    # path is the split grouping above)
+    known = {0: [0.8236475079774124, 0.9103565379264364, 0.16456579813368521],
+             1: [0.23603334566204692, 0.34651701419196046, 0.3127069683360675],
+             1234: [0.5908446386657102, 0.7667970365022592, 0.5662374165061859]}
+    for seed, vals in known.items():
+        g = MersenneTwister(seed)
+        assert [g.rand() for _ in range(3)] == vals, seed
     r = MersenneTwister(1)
     assert r.rand() == 0.23603334566204692
     assert [MersenneTwister(1).rand() for _ in range(2)] == [0.23603334566204692] * 2
