@@ -956,16 +956,20 @@ __global__ void __launch_bounds__(1024) transfer_wide2_kernel(TransferArgs<float
     raw_load(g + 1, ra, rc);                            // (clamped past the end of the row: always safe, never a branch)
     unsigned* m = reinterpret_cast<unsigned*>(tb + lane * 12);
     m[0] = (unsigned)b; m[1] = (unsigned)n; m[2] = __float_as_uint(cf);
-    const unsigned long long m1 = __ballot(n > 64), m2 = __ballot(n > 80);
+    // list 1 holds the first 48 features longer than 64 entries (steps 16..18), list 2 the first 16 of THOSE that are
+    // longer than 80 (step 19): a feature that found no place in list 1 must not appear in list 2 -- its owner adds
+    // everything past entry 64 itself, and step 19 would add entries 80..95 a second time
+    const unsigned long long m1 = __ballot(n > 64);
     const int r1 = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+    const bool in1 = n > 64 && r1 < 48;
+    const unsigned long long m2 = __ballot(in1 && n > 80);
     const int r2 = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u));
+    const bool in2 = in1 && n > 80 && r2 < 16;
     l1[lane] = 255; l2[lane] = 255;                      // 255 = no feature at this list position
-    if (n > 64) l1[r1] = (unsigned char)lane;
-    if (n > 80) l2[r2] = (unsigned char)lane;
+    if (in1) l1[r1] = (unsigned char)lane;
+    if (in2) l2[r2] = (unsigned char)lane;
     // the rare rest: entries the 20 steps do not reach, added by the owning lane
-    int cov = 64;
-    if (n > 64 && r1 < 48) cov = 80;
-    if (cov == 80 && n > 80 && r2 < 16) cov = 96;
+    const int cov = in2 ? 96 : (in1 ? 80 : 64);
     if (__ballot(n > cov) != 0ull) {
       for (int x = cov; x < n; ++x) {
         const int at = 4 * b + x;

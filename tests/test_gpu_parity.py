@@ -941,18 +941,20 @@ def test_tutorial_example_runs_end_to_end_on_the_device():
     {"SS_TRANSFER_V": "1", "SS_TRANSFER_FIX1": "1"},                   # single-wave kernel with fixed-point sums
     {"SS_TRANSFER_V": "1", "SS_TRANSFER_LD": "1"},                     # single-wave kernel with buffer loads
 ])
-@pytest.mark.parametrize("chunk", [None, "3000"])
-def test_stage1_variants_match_the_oracle(variant, chunk, monkeypatch):
+@pytest.mark.parametrize("chunk,dx", [(None, 0.05), ("3000", 0.05), ("500", 0.2)])
+def test_stage1_variants_match_the_oracle(variant, chunk, dx, monkeypatch):
     """The measured-but-not-default stage-1 kernels against the CPU oracle: default chunking
-    (short sub-rows) and one 3000-column chunk (150-entry sub-rows: second and third levels of the wide kernels, their
-    per-lane rest path past 96 entries).  Zero-degree features, an empty query row, weighted and unweighted features.
+    (short sub-rows), one 3000-column chunk (150-entry sub-rows: second and third levels of the wide kernels, their
+    per-lane rest path past 96 entries) and 20 % fill in 500-column chunks (EVERY sub-row ~100 entries: the lists of the
+    second and third levels overflow in every group of 64 features -- the case tools/fuzz_predict.py found a double count
+    in).  Zero-degree features, an empty query row, weighted and unweighted features.
     Fixed-point sums: error bound n_terms * 2^-30 * (sum |coefficients|) * max |value| per score."""
     for k, v in variant.items():
         monkeypatch.setenv(k, v)
     if chunk:
         monkeypatch.setenv("SS_TRANSFER_CHUNK", chunk)
     for weighted in (True, False):
-        Xq, Xs, Ys = O.synth_bipartite(257, 3000, 3000, 200, 0.05, 0.03, seed=11, weighted=weighted, dtype=np.float32)
+        Xq, Xs, Ys = O.synth_bipartite(257, 3000, 3000, 200, dx, 0.03, seed=11, weighted=weighted, dtype=np.float32)
         Xq = Xq.tolil(); Xq[5, :] = 0; Xq = Xq.tocsr()                     # a query without features
         Xs = Xs.tolil(); Xs[:, 17] = 0; Xs[:, 18] = 0; Xs = Xs.tocsr()     # features nobody has (degree 0)
         g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)

@@ -63,11 +63,12 @@ def rand_graph(rng, dtype):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20250222
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else None   # replay one case of a seed (the draws before it are repeated, not scored)
     rng = np.random.default_rng(seed)
     ss.init(0)
     t0 = time.time()
     cases, worst32, worst64, kinds, paths = 0, 0.0, 0.0, {}, {}
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (only is None or cases <= only):
         dtype = np.float32 if rng.random() < 0.6 else np.float64
         env = {}
         for k, choices in SWITCHES.items():
@@ -78,6 +79,18 @@ def main():
                 env[k] = v
         Xq, Xs, Ys, weighted = rand_graph(rng, dtype)
         f64 = [m.astype(np.float64) for m in (Xq, Xs, Ys)]
+        if only is not None and cases != only:
+            rng.random()
+            if Xs.shape[0] == Xs.shape[1] and rng.random() < 0.7:
+                lo = int(rng.integers(0, Xs.shape[0])); int(rng.integers(lo, Xs.shape[0]))
+                if Xs.shape[0] <= 3000:
+                    rng.integers(0, Xs.shape[0], size=6)
+            cases += 1
+            continue
+        if only is not None:
+            print("replaying", dict(env=env, shapes=(Xq.shape, Xs.shape, Ys.shape), nnz=(Xq.nnz, Xs.nnz, Ys.nnz), weighted=weighted, dtype=str(dtype)), flush=True)
+            if os.environ.get("FUZZ_SAVE"):
+                sp.save_npz(os.environ["FUZZ_SAVE"] + "_xq.npz", Xq); sp.save_npz(os.environ["FUZZ_SAVE"] + "_xs.npz", Xs); sp.save_npz(os.environ["FUZZ_SAVE"] + "_ys.npz", Ys)
         g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=dtype)
         tol = 1e-5 if dtype == np.float32 else 1e-12
         kt = np.asarray((f64[2] != 0).sum(0)).ravel()
