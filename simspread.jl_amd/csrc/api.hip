@@ -829,8 +829,30 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
     const int rowb = B * (int64_t)sizeof(T) <= 64 ? 64 : (B * (int64_t)sizeof(T) <= 128 ? 128 : 256);
     const int slot = rowb == 64 ? 0 : (rowb == 128 ? 1 : 2);
     const int bv = rowb / (int)sizeof(T);
+    // fp32: the lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip, round 3); SS_CSELL=0: the 2-D kernel
+    bool done = false;
+    if constexpr (sizeof(T) == 4) {
+      if (!(getenv("SS_CSELL") && atoi(getenv("SS_CSELL")) == 0)) {
+        DevCsell& cs = m.csell[slot];
+        if (!m.csell_tried[slot]) {
+          int kc = csell_chunk_cols(bv);
+          if (const char* e = getenv("SS_NARROW_CHUNK")) {
+            const int v = atoi(e);
+            if (v >= 16 && v < kc) kc = v;
+          }
+          SS_TRY(csell_build(m.csr, kc, bv, cs));
+          m.csell_tried[slot] = true;
+        }
+        if (cs.ok) {
+          StageTimer t2(ST_SPMM);
+          SS_TRY(launch_spmm_csell(cs, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
+          timing_count(ST_NSPMM, 1);
+          done = true;
+        }
+      }
+    }
     DevChunked<T>& op = m.col[slot];
-    if (op.SC == 0) {
+    if (!done && op.SC == 0) {
       int kc = colgroup_chunk_cols<T>(bv);
       if (const char* e = getenv("SS_NARROW_CHUNK")) {
         const int v = atoi(e);
@@ -838,9 +860,11 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
       }
       SS_TRY(chunked_build<T>(m.csr, kc, 4, op));
     }
-    StageTimer t2(ST_SPMM);
-    SS_TRY(launch_spmm_colgroup<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
-    timing_count(ST_NSPMM, 1);
+    if (!done) {
+      StageTimer t2(ST_SPMM);
+      SS_TRY(launch_spmm_colgroup<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
+      timing_count(ST_NSPMM, 1);
+    }
   } else if (narrow) {
     int slot = 0, bv = 1;
     while (bv < B) { bv <<= 1; ++slot; }

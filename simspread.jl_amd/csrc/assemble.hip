@@ -711,6 +711,201 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   return SS_OK;
 }
 
+// ------------------------------------------------------------------ CSR -> compact sliced ELL (spmm_csell.hip)
+// entries of row `row` inside chunk [k0, k0 + KC): first CSR position and count
+__device__ __forceinline__ void csell_subrow(const int* __restrict__ ptr, const int* __restrict__ idx, int64_t row,
+                                             int64_t rows, int64_t k0, int KC, int& first, int& n) {
+  first = 0; n = 0;
+  if (row < rows) {
+    const int lo = ptr[row], hi = ptr[row + 1];
+    const int64_t k1 = k0 + KC;
+    int a = lo, b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k0) a = m + 1; else b = m; }
+    first = a;
+    b = hi;
+    while (a < b) { const int m = (a + b) >> 1; if (idx[m] < k1) a = m + 1; else b = m; }
+    n = a - first;
+  }
+}
+
+// one wave per block (chunk, slice): pairs per lane, steps of the block (its longest lane) and its pairs
+__global__ void __launch_bounds__(64) csell_count_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                         int64_t rows, int KC, int nslices, int64_t nblocks,
+                                                         unsigned short* __restrict__ np, int* __restrict__ steps,
+                                                         int* __restrict__ pairs) {
+  const int lane = threadIdx.x;
+  for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int c = (int)(b / nslices), s = (int)(b % nslices);
+    int first, n;
+    csell_subrow(ptr, idx, (int64_t)s * 64 + lane, rows, (int64_t)c * KC, KC, first, n);
+    const int p = (n + 1) >> 1;
+    np[b * 64 + lane] = (unsigned short)p;
+    int mx = p, sm = p;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int m2 = __shfl_xor(mx, o);
+      mx = m2 > mx ? m2 : mx;
+      sm += __shfl_xor(sm, o);
+    }
+    if (lane == 0) { steps[b] = mx; pairs[b] = sm; }
+  }
+}
+
+__global__ void csell_desc_kernel(const int* __restrict__ base, const int* __restrict__ steps, int64_t nblocks,
+                                  int* __restrict__ desc) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= nblocks; b += (int64_t)gridDim.x * blockDim.x) {
+    desc[2 * b] = base[b];                       // base[nblocks] = all pairs: the empty block past the end
+    desc[2 * b + 1] = b < nblocks ? steps[b] : 0;
+  }
+}
+
+// One wave per block: writes the block's pairs in step order.  The order of a lane's entries is free; for tile rows
+// narrower than an LDS line (QT = 16, 32: 4 / 2 tile rows per 256 bytes) it is scheduled position by position: the lanes
+// that read the same 16-byte slot number in the same LDS cycle (same lane & (QT/4 - 1) inside one of the four 16-lane
+// groups ds_read_b128 is served in) take tile rows of different classes (k mod 4 / k mod 2), largest remaining class first,
+// rotating priority; a lane with nothing else left takes a conflicting entry.
+template <int QT>
+__global__ void __launch_bounds__(64) csell_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                        const float* __restrict__ val, int64_t rows, int KC, int nslices,
+                                                        int64_t nblocks, const int* __restrict__ desc, int* __restrict__ perm,
+                                                        unsigned short* __restrict__ pidx16, float* __restrict__ pval) {
+  constexpr int NPC = QT / 4, NCL = 64 / QT;
+  __shared__ unsigned short cnt[64][NCL + 1];
+  __shared__ int cur[64][NCL + 1];
+  const int lane = threadIdx.x;
+  int grp, gi;
+  b128_group_of_lane(lane, grp, gi);
+  for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int c = (int)(b / nslices), s = (int)(b % nslices);
+    const int64_t k0 = (int64_t)c * KC;
+    int first, n;
+    csell_subrow(ptr, idx, (int64_t)s * 64 + lane, rows, k0, KC, first, n);
+    const int64_t base = desc[2 * b];
+    const int steps = desc[2 * b + 1];
+    const int npl = (n + 1) >> 1;
+    if (NCL > 1) {
+      for (int q = 0; q < NCL; ++q) cnt[lane][q] = 0;
+      for (int x = 0; x < n; ++x) cnt[lane][(idx[first + x] - k0) & (NCL - 1)]++;
+      int run = first;
+      for (int q = 0; q < NCL; ++q) { cur[lane][q] = run; run += cnt[lane][q]; }
+      for (int x = 0; x < n; ++x) {
+        const int q = (int)((idx[first + x] - k0) & (NCL - 1));
+        perm[cur[lane][q]++] = first + x;
+      }
+      for (int q = 0; q < NCL; ++q) cur[lane][q] -= cnt[lane][q];
+    }
+    int left = n;
+    int64_t runp = 0;
+    unsigned long long mask = 0ull;
+    int rank = 0;
+    for (int t = 0; t < 2 * steps; ++t) {
+      int e = -1;   // CSR position of the entry this lane puts at position t
+      if (NCL == 1) {
+        if (t < n) e = first + t;
+      } else {
+        unsigned claimed = 0;
+        int mine = -1;
+        for (int i = 0; i < 16; ++i) {
+          const int turn = (i + t) & 15;
+          const int chooser = b128_lane_of_group(grp, turn);
+          int choice = -1;
+          if (gi == turn && left > 0) {
+            const int pid = lane & (NPC - 1);
+            int best = -1, bestc = 0;
+            for (int q = 0; q < NCL; ++q) {
+              const int cq = cnt[lane][q];
+              if (cq > bestc && !((claimed >> (pid * NCL + q)) & 1u)) { best = q; bestc = cq; }
+            }
+            if (best < 0)
+              for (int q = 0; q < NCL; ++q) {
+                const int cq = cnt[lane][q];
+                if (cq > bestc) { best = q; bestc = cq; }
+              }
+            choice = best;
+            mine = best;
+          }
+          const int ch = __shfl(choice, chooser);
+          if (ch >= 0) claimed |= 1u << ((chooser & (NPC - 1)) * NCL + ch);
+        }
+        if (mine >= 0) {
+          e = perm[cur[lane][mine]];
+          cur[lane][mine]++;
+          cnt[lane][mine]--;
+          --left;
+        }
+      }
+      const int u = t >> 1, half = t & 1;
+      const bool act = npl > u;
+      if (half == 0) {
+        mask = __ballot(act);
+        rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      }
+      if (act) {
+        const int64_t at = (base + runp + rank) * 2 + half;
+        pidx16[at] = e >= 0 ? (unsigned short)(idx[e] - k0) : (unsigned short)KC;
+        if (pval) pval[at] = e >= 0 ? val[e] : 0.f;
+      }
+      if (half == 1) runp += __builtin_popcountll(mask);
+    }
+  }
+}
+
+int csell_build(const DevCsr<float>& in, int KC, int QT, DevCsell& out) {
+  hipStream_t st = ctx().stream;
+  if (KC < 1 || KC > 32767) return fail(SS_EINVAL, "compact sliced ELL: chunk size out of range");
+  if (QT != 16 && QT != 32 && QT != 64) return fail(SS_EINVAL, "compact sliced ELL: tile width must be 16, 32 or 64");
+  out.ok = false;
+  out.rows = in.rows; out.cols = in.cols; out.nnz = in.nnz; out.binary = in.binary;
+  out.KC = KC; out.QT = QT;
+  out.nchunks = (int)(in.cols > 0 ? ceil_div(in.cols, KC) : 1);
+  out.nslices = (int)ceil_div(in.rows, 64);
+  const int64_t nblocks = (int64_t)out.nchunks * out.nslices;
+  if (nblocks <= 0 || nblocks >= (1LL << 24)) return SS_OK;   // (the 2-D kernel serves what does not fit here)
+  DevBuf<int> steps, pairs, base;
+  SS_TRY(out.np.alloc((size_t)(nblocks + 1) * 64));
+  SS_TRY(steps.alloc(nblocks + 1));
+  SS_TRY(pairs.alloc(nblocks + 1));
+  SS_TRY(base.alloc(nblocks + 2));
+  SS_HIP(hipMemsetAsync(out.np.p + (size_t)nblocks * 64, 0, 64 * sizeof(unsigned short), st));
+  const unsigned grid = (unsigned)(nblocks < (1 << 20) ? nblocks : (1 << 20));
+  hipLaunchKernelGGL(csell_count_kernel, dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.rows, KC, out.nslices,
+                     nblocks, out.np.p, steps.p, pairs.p);
+  SS_LAUNCH_CHECK();
+  SS_TRY(exclusive_scan_int(pairs.p, base.p, nblocks));
+  int total = 0;
+  SS_TRY(read_int(base.p + nblocks, &total));
+  if (total < 0) return SS_OK;
+  out.npairs = total;
+  SS_TRY(out.desc.alloc((size_t)(nblocks + 1) * 2));
+  hipLaunchKernelGGL(csell_desc_kernel, dim3(grid_for(nblocks + 1, 256)), dim3(256), 0, st, base.p, steps.p, nblocks, out.desc.p);
+  SS_LAUNCH_CHECK();
+  SS_TRY(out.pidx.alloc((size_t)total + 64));
+  SS_HIP(hipMemsetAsync(out.pidx.p + total, 0, 64 * sizeof(unsigned), st));
+  if (!in.binary) {
+    SS_TRY(out.pval.alloc(2 * ((size_t)total + 64)));
+    SS_HIP(hipMemsetAsync(out.pval.p + 2 * (size_t)total, 0, 128 * sizeof(float), st));
+  } else {
+    out.pval.release();
+  }
+  DevBuf<int> perm;
+  if (QT < 64) SS_TRY(perm.alloc(in.nnz));
+  unsigned short* p16 = reinterpret_cast<unsigned short*>(out.pidx.p);
+  float* pv = in.binary ? (float*)nullptr : out.pval.p;
+  if (QT == 16)
+    hipLaunchKernelGGL(csell_fill_kernel<16>, dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
+                       out.nslices, nblocks, out.desc.p, perm.p, p16, pv);
+  else if (QT == 32)
+    hipLaunchKernelGGL(csell_fill_kernel<32>, dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
+                       out.nslices, nblocks, out.desc.p, perm.p, p16, pv);
+  else
+    hipLaunchKernelGGL(csell_fill_kernel<64>, dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
+                       out.nslices, nblocks, out.desc.p, perm.p, p16, pv);
+  SS_LAUNCH_CHECK();
+  SS_HIP(hipStreamSynchronize(st));   // perm and the counters are freed on return
+  out.ok = true;
+  return SS_OK;
+}
+
 // largest and smallest non-zero |value| of an array, as fp32 bit patterns (non-negative floats order like integers)
 template <class T>
 __global__ void abs_range_kernel(const T* __restrict__ v, int64_t n, int* __restrict__ mm) {

@@ -63,6 +63,26 @@ struct DevChunked {
   float vmax = 0.f, vmin = 0.f;  // largest / smallest non-zero |value|
 };
 
+// Mid-width W*R operand of round 3 (spmm_csell.hip): "compact sliced ELL".  Rows in slices of 64 (one lane per row),
+// columns in chunks of KC (one LDS tile of R); block (chunk c, slice s) = c*nslices + s stores its entries pair by pair:
+// step u holds entries 2u, 2u+1 of every lane whose sub-row has them, lanes in ascending order, nothing for the others,
+// so a wave step is one coalesced 4-byte (two 16-bit local indices) and one 8-byte (two values) load per lane and memory
+// holds no padding except the odd last entry of a sub-row (index KC = the zero row of the tile, value 0).  The order of
+// the entries inside a sub-row is chosen when the operand is built so that lanes which read the same 16-byte slot of an
+// LDS line in the same cycle hold tile rows of different bank classes (tile rows narrower than 256 bytes).
+struct DevCsell {
+  int64_t rows = 0, cols = 0, nnz = 0;
+  int KC = 0, nchunks = 0, nslices = 0;
+  int QT = 0;                     // tile width (columns of R per tile row) the entry order was scheduled for: 16, 32, 64
+  bool binary = false;            // every value 1: no value stream
+  bool ok = false;                // built (false: not yet, or the matrix does not fit the format -> the 2-D kernel serves it)
+  int64_t npairs = 0;
+  DevBuf<int> desc;               // [nblocks + 1][2] {first pair, steps}; the last block is empty
+  DevBuf<unsigned short> np;      // [(nblocks + 1) * 64] pairs per lane
+  DevBuf<unsigned> pidx;          // [npairs + 64]
+  DevBuf<float> pval;             // [2 * (npairs + 64)] unless binary
+};
+
 // Dense-similarity regime: the raw similarities stay dense on the device (column-major), the cutoff is
 // applied inside the stage-1 GEMM (dense.hip).
 template <class T>
@@ -108,6 +128,8 @@ struct SpMat {
   int sell_qt = 0;
   DevChunked<T> narrow[3];  // quad-aligned chunked operands of the narrow kernel for B <= 1, 2, 4 (built lazily)
   DevChunked<T> col[3];     // operands of the 2-D kernel: 64-, 128- and 256-byte tile rows (built lazily)
+  DevCsell csell[3];        // fp32: operands of the lane-per-row kernel for 16, 32 and 64 columns (built lazily)
+  bool csell_tried[3] = {false, false, false};
   DevBuf<T> partial;        // partial sums of the narrow / 2-D kernels (and the padded copy of R, spmm_colgroup.hip)
 };
 
@@ -124,6 +146,7 @@ template <class T>
 int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out);
 template <class T>
 int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out);
+int csell_build(const DevCsr<float>& in, int KC, int QT, DevCsell& out);   // out.ok == false: not representable (no error)
 template <class T>
 int graph_finalize(Graph<T>& g);  // transposes + degrees
 template <class T>
@@ -190,6 +213,9 @@ int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64
 // stage 2, mid width (5 <= B, B*sizeof(T) <= 256 bytes): 2-D cut (row blocks x chunk groups) with conflict-free gathers
 // (spmm_colgroup.hip): tile rows of 64, 128 or 256 bytes (fp32: B <= 16, 32, 64; fp64: B <= 8, 16, 32); same chunked
 // operand format as the narrow kernel
+// ---- spmm_csell.hip (fp32, 5 <= B <= 64, row-major R and F)
+int csell_chunk_cols(int qt);   // tile rows that fit in LDS next to the zero row
+int launch_spmm_csell(const DevCsell& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf, DevBuf<float>& partial);
 template <class T>
 int colgroup_chunk_cols(int bv);
 template <class T>

@@ -548,10 +548,10 @@ def test_spmm_narrow_every_group_size(mean_entries, dtype):
 @pytest.mark.parametrize("dtype,B", [(np.float32, 12), (np.float32, 16), (np.float32, 28), (np.float32, 64), (np.float32, 52),
                                      (np.float64, 6), (np.float64, 16), (np.float64, 32)])
 def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
-    """Mid width (fp32 5 <= B <= 64, fp64 5 <= B <= 32): the 2-D kernel (spmm_colgroup.hip).  Several row blocks,
-    several chunk groups (partial sums combined in fixed order), several LDS chunks of R per group, sub-rows longer
-    than the prefetched batches (row 7 is full) and empty rows; must agree with scipy and with the SELL kernel, and
-    be bitwise repeatable."""
+    """Mid width (fp32 5 <= B <= 64, fp64 5 <= B <= 32): the 2-D kernel (spmm_colgroup.hip; fp32 reaches it under
+    SS_CSELL=0 since round 3).  Several row blocks, several chunk groups (partial sums combined in fixed order), several
+    LDS chunks of R per group, sub-rows longer than the prefetched batches (row 7 is full) and empty rows; must agree with
+    scipy and with the SELL kernel, and be bitwise repeatable."""
     rng = np.random.default_rng(100 + B)
     M, K = 9011, 2900
     W = sp.random(M, K, density=0.012, format="lil", random_state=rng, dtype=np.float64)
@@ -562,12 +562,14 @@ def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
     W.eliminate_zeros()
     R = rng.standard_normal((K, B))
     want = W @ R
+    monkeypatch.setenv("SS_CSELL", "0")
     monkeypatch.setenv("SS_NARROW_CHUNK", "500")     # 6 chunks of R
     monkeypatch.setenv("SS_COL_FROM", "5")           # also the pattern-only wide cases stay on this kernel
     for cg in ("1", "3"):
         monkeypatch.setenv("SS_COL_CG", cg)
         w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
         got = w.spmm(R.astype(dtype))
+        assert "spmm_colgroup" in ss.path_last()
         assert_close_signed(got, want, dtype)
         assert np.array_equal(got, w.spmm(R.astype(dtype)))
     monkeypatch.setenv("SS_COL", "0")
@@ -575,10 +577,71 @@ def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
     assert_close_signed(ss.DeviceSpMat(W.astype(dtype), dtype=dtype).spmm(R.astype(dtype)), want, dtype)
 
 
+@pytest.mark.parametrize("binary", [False, True])
+@pytest.mark.parametrize("B", [5, 12, 16, 17, 28, 32, 33, 52, 64])
+def test_spmm_csell_lane_per_row(B, binary, monkeypatch):
+    """fp32 mid width since round 3: the lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip,
+    csell_build in assemble.hip).  Row count no multiple of 64, empty rows, a FULL row (a 500-entry sub-row in every
+    chunk: 250 steps in a block whose other lanes have ~3), an odd-length tail in most sub-rows (pad entry -> zero tile
+    row), 6 chunks of R, widths that need the padded copy of R and scalar stores (5, 17, 33), several cuts (slices per
+    workgroup, chunk groups: partial sums in fixed order, row sets of a wave beyond the workgroup's slices, blocks past the
+    end of a wave's list).  Against scipy, against the 2-D kernel to rounding, bitwise repeatable, and every cut must
+    give the same bits when it has one chunk group (the entry order is the operand's, not the cut's)."""
+    rng = np.random.default_rng(300 + B)
+    M, K = 9011, 2900
+    W = sp.random(M, K, density=0.012, format="lil", random_state=rng, dtype=np.float64)
+    W[7, :] = 1.0
+    W[100:130, :] = 0.0
+    W[M - 1, :] = 0.0
+    W[M - 1, K - 1] = 1.0
+    W = W.tocsr()
+    W.data = np.ones(W.nnz) if binary else rng.random(W.nnz) + 0.5
+    W.eliminate_zeros()
+    R = rng.standard_normal((K, B))
+    want = W @ R
+    monkeypatch.setenv("SS_NARROW_CHUNK", "500")
+    monkeypatch.setenv("SS_COL_FROM", "5")           # pattern-only wide cases too
+    one_group = []
+    for cut in (None, "3,1", "7,2", "1,6", "16,1"):
+        if cut:
+            monkeypatch.setenv("SS_CSELL_CUT", cut)
+        w = ss.DeviceSpMat(W.astype(np.float32), dtype=np.float32)
+        got = w.spmm(R.astype(np.float32))
+        assert "spmm_csell" in ss.path_last(), ss.path_last()
+        assert_close_signed(got, want, np.float32)
+        assert np.array_equal(got, w.spmm(R.astype(np.float32)))
+        if cut and cut.endswith(",1"):
+            one_group.append(got)
+    assert np.array_equal(one_group[0], one_group[1])
+    monkeypatch.delenv("SS_CSELL_CUT")
+    monkeypatch.setenv("SS_CSELL", "0")
+    w0 = ss.DeviceSpMat(W.astype(np.float32), dtype=np.float32)
+    other = w0.spmm(R.astype(np.float32))
+    assert "spmm_colgroup" in ss.path_last()
+    assert_close_signed(other, want, np.float32)
+
+
+def test_spmm_csell_tiny_and_degenerate_shapes():
+    """One row, one column, an all-zero matrix, fewer rows than a slice, K smaller than a chunk."""
+    rng = np.random.default_rng(5)
+    for M, K, dens in ((1, 1, 1.0), (1, 300, 0.5), (63, 7, 0.3), (65, 2561, 0.01), (200, 40, 0.0)):
+        W = sp.random(M, K, density=dens, format="csr", random_state=rng, dtype=np.float64)
+        W.data = rng.random(W.nnz) + 0.5
+        for B in (8, 16, 40, 64):
+            R = rng.standard_normal((K, B))
+            w = ss.DeviceSpMat(W.astype(np.float32), dtype=np.float32)
+            got = w.spmm(R.astype(np.float32))
+            if W.nnz:                                  # (an empty matrix counts as pattern-only: wide B goes to the SELL kernel)
+                assert "spmm_csell" in ss.path_last()
+            want = W @ R
+            assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0)
+
+
 @pytest.mark.parametrize("dtype,B", [(np.float32, 5), (np.float32, 7), (np.float32, 9), (np.float32, 16), (np.float32, 24),
                                      (np.float32, 50), (np.float64, 5), (np.float64, 12), (np.float64, 31)])
 def test_spmm_width_routing(dtype, B, monkeypatch):
-    """Row-major operands: B <= 4 narrow kernel, 5 <= B (B * sizeof <= 256 bytes) the 2-D kernel, wider the SELL kernel.
+    """Row-major operands: B <= 4 narrow kernel, 5 <= B (B * sizeof <= 256 bytes) the lane-per-row kernel (fp32) or the 2-D
+    kernel (fp64), wider the SELL kernel.
     Widths that cannot be staged in 16-byte pieces (B = 5, 7, 9, 31; a leading dimension that is no multiple of 16
     bytes) go through the padded copy of R; SS_COL=0 (SELL kernel) must agree to rounding; results are bitwise
     repeatable (fixed summation order)."""
@@ -591,7 +654,7 @@ def test_spmm_width_routing(dtype, B, monkeypatch):
     monkeypatch.setenv("SS_NARROW_CHUNK", "600")     # 5 chunks of R
     w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
     got = w.spmm(R.astype(dtype))
-    assert "spmm_colgroup" in ss.path_last()
+    assert ("spmm_csell" if dtype == np.float32 else "spmm_colgroup") in ss.path_last()
     assert_close_signed(got, want, dtype)
     assert np.array_equal(got, w.spmm(R.astype(dtype)))
     for b, name in ((4, "spmm_chunked_narrow"), (3, "spmm_chunked_narrow"), (80, "spmm_sell")):

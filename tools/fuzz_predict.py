@@ -66,7 +66,7 @@ def main():
     only = int(sys.argv[3]) if len(sys.argv) > 3 else None   # replay one case of a seed (the draws before it are repeated, not scored)
     rng = np.random.default_rng(seed)
     ss.init(0)
-    t0 = time.time()
+    t0 = last = time.time()
     cases, worst32, worst64, kinds, paths = 0, 0.0, 0.0, {}, {}
     while time.time() - t0 < budget and (only is None or cases <= only):
         dtype = np.float32 if rng.random() < 0.6 else np.float64
@@ -130,6 +130,9 @@ def main():
             kinds[name] = kinds.get(name, 0) + 1
         g.close()
         cases += 1
+        if time.time() - last > 45:
+            last = time.time()
+            print(f"[{last - t0:.0f} s] {cases} graphs ok", flush=True)
     for k in SWITCHES:
         os.environ.pop(k, None)
     print(json.dumps({"seconds": round(time.time() - t0, 1), "seed": seed, "graphs": cases, "checks": kinds, "kernels_taken": paths,

@@ -37,7 +37,7 @@ for d in find("pmc_*/"):
             for r in csv.DictReader(fh):
                 agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in agg.items():
-            if not any(s in k for s in ("transfer", "spmm", "reduce_kernel", "unpermute")):
+            if not any(s in k for s in ("transfer", "spmm", "reduce_kernel", "unpermute", "csell")):
                 continue
             print(k[:70])
             for cn, vals in sorted(cs.items()):
