@@ -242,7 +242,9 @@ int ss_predict_kfold_f64(ss_graph* g, const int32_t* fold_of_source, int nfolds,
 
 /* Ranked evaluation without moving the scores ("next" row of the scope table: recallatL / precisionatL,
  * src/performance.jl:308-385): for every row of a row-major score block the L best columns in the order
- * sortperm(yhat, rev=true) gives (score descending, ties by ascending column).  idx and val are nrows x L,
+ * sortperm(yhat, rev=true) gives (score descending, ties by ascending column; as Julia's isless orders floats, +0.0 ranks
+ * before -0.0 -- SimSpread scores are sums of non-negative products and clean!'s -99, so -0.0 does not occur in them).
+ * idx and val are nrows x L,
  * row-major; L <= 1024 and L <= ncols.  With the labels of those columns recall@L and precision@L follow on
  * the host from nrows*L numbers instead of nrows*ncols scores. */
 int ss_topl_f32(const float* scores, int64_t nrows, int64_t ncols, int64_t ld, int L,

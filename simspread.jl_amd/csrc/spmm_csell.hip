@@ -57,7 +57,7 @@ template <int QT, bool BIN, int D>
 __global__ void __launch_bounds__(CSELL_WAVES * 64) spmm_csell_kernel(CsArgs a) {
   constexpr int NPS = csell_nps(QT);
   constexpr int ROWB = QT * 4, NPC = QT / 4;
-  constexpr int NB = 4;                      // LDS reads per batch: one batch in flight while the one before is multiplied
+  constexpr int NB = QT == 32 ? 2 : 4;       // LDS reads per batch: one batch in flight while the one before is multiplied
   constexpr int RSH = ROWB == 256 ? 8 : (ROWB == 128 ? 7 : 6);
   extern __shared__ __align__(16) unsigned char tb[];   // the tile [KC + 1][ROWB] at LDS offset 0 (no static LDS here)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -137,10 +137,11 @@ __global__ void __launch_bounds__(CSELL_WAVES * 64) spmm_csell_kernel(CsArgs a) 
 #pragma unroll
         for (int d = 0; d < D; ++d) {
           if (u0 + d < nst_cur) {   // wave-uniform
-            const bool act = np_cur > u0 + d;
+            // lanes without this pair sit the step out (EXEC): reading the zero row instead would cost them nothing, but
+            // the zero row has a bank class too and they would collide with the active lanes of their slot number
+            if (np_cur <= u0 + d) continue;
             const unsigned x = pi[d];
-            const unsigned ka = act ? (x & 0xffffu) : (unsigned)a.KC;   // lanes without this pair: the zero row
-            const unsigned kb = act ? (x >> 16) : (unsigned)a.KC;
+            const unsigned ka = x & 0xffffu, kb = x >> 16;
             const unsigned basea = (ka << RSH) | lanebits, baseb = (kb << RSH) | lanebits;
             const float wa = BIN ? 1.f : pv[d].x, wb = BIN ? 1.f : pv[d].y;
             constexpr int NIT = 2 * NPC, NBAT = NIT / NB;

@@ -860,6 +860,24 @@ def test_topl_matches_stable_descending_sort_with_ties():
         np.testing.assert_array_equal(val, np.take_along_axis(x, want, 1))
 
 
+def test_topl_signed_zeros_rank_as_julia_isless_orders_them(monkeypatch):
+    """sortperm(yhat, rev=true) compares with isless, for which -0.0 < +0.0: +0.0 columns come first (ascending), then the
+    -0.0 columns (include/simspread_hip.h, ss_topl_f32).  numpy's argsort(-x) calls the two zeros equal -- the difference
+    tools/fuzz_spmm_topl.py stumbled over; SimSpread scores hold no -0.0."""
+    x = np.zeros((2, 3000), np.float32)
+    x[0, ::2] = -0.0
+    x[0, 5] = 1.0
+    x[1, 1000:] = -0.0
+    x[1, 7] = -1.0
+    odd = [c for c in range(1, 3000, 2) if c != 5]
+    for bound in ("1", "0"):                            # fast path and radix select alone
+        monkeypatch.setenv("SS_TOPL_BOUND", bound)
+        idx, val = ss.topl(x, 1024)
+        assert idx[0].tolist() == [5] + odd[:1023]
+        assert idx[1].tolist() == [c for c in range(1000) if c != 7] + list(range(1000, 1025))
+        assert not np.signbit(val[1, :999]).any() and np.signbit(val[1, 999:]).all()
+
+
 def test_topl_bound_path_and_radix_fallback_agree(monkeypatch):
     """ss_topl_f32 has a fast path (lower bound from per-thread maxima, candidates sorted) and a radix-select fallback for
     rows with more than 4096 candidates: distinct scores stay on the fast path, long runs of equal scores at the bound

@@ -48,7 +48,12 @@ def main():
         if mode == 3: x[rng.integers(0, rows)] = -99.0
         L = int(min(n, rng.choice([1, 5, 100, 1000, 1024])))
         idx, val = ss.topl(x, L)
-        want = np.argsort(-x, axis=1, kind="stable")[:, :L]
+        # sortperm(x, rev=true) as Julia orders floats (isless): score descending, +0.0 before -0.0, ties by ascending column
+        # (numpy's argsort(-x) calls +0.0 and -0.0 equal: seed 7 found that difference, it is the test's, not the kernel's)
+        u = x.view(np.uint32)
+        key = np.where(u & 0x80000000, ~u, u | np.uint32(0x80000000)).astype(np.uint64)
+        comp = (key << np.uint64(32)) | (~np.arange(n, dtype=np.uint32)).astype(np.uint64)
+        want = np.argsort(comp, axis=1)[:, ::-1][:, :L]
         assert np.array_equal(idx, want), (case, rows, n, L, mode)
         assert np.array_equal(val, np.take_along_axis(x, want, 1))
     print("topl: %d cases ok" % (ncases // 3))

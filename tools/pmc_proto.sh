@@ -13,8 +13,8 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
   echo "pass $i: $grp" >> $OUT/progress.txt
-  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $RAW/pmc_g$i -- python3 tools/csell_proto.py "$@" > $OUT/pmc_g$i.log 2>&1
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $RAW/pmc_g$i -- python3 ${PMC_SCRIPT:-tools/csell_proto.py} "$@" > $OUT/pmc_g$i.log 2>&1
   echo "   rc $?" >> $OUT/progress.txt
 done
 python3 tools/prof_summary.py $RAW > $OUT/summary.txt 2>&1
-grep -A12 "csell_kernel\|spmm_colgroup_kernel" $OUT/summary.txt | cut -c1-120
+grep -A12 "csell\|spmm_colgroup_kernel" $OUT/summary.txt | cut -c1-120
