@@ -812,8 +812,9 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   // Routing by width, row-major operands (measured at 100k x 100k / 1 %):
   //   B <= 4                          narrow kernel: W streamed once, the chunk of R in LDS, lanes of a row folded -- the
   //                                   HBM-bound regime (B = 1 0.13 ms = 4.6 TB/s of the 6 B/nnz operand)
-  //   5 <= B, B*sizeof(T) <= 256 B    2-D kernel (spmm_colgroup.hip): tile rows of 64 / 128 / 256 bytes (fp32 B <= 64, fp64 <= 32);
-  //                                   B = 5..16 0.22-0.24 ms, 32 0.44, 64 0.9
+  //   5 <= B, B*sizeof(T) <= 256 B    fp32: lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip; B = 8 / 16 / 32 / 64
+  //                                   0.19 / 0.18 / 0.35 / 0.70 ms); fp64 (and SS_CSELL=0): 2-D kernel (spmm_colgroup.hip), tile rows
+  //                                   of 64 / 128 / 256 bytes; fp32 B = 5..16 0.22-0.24 ms, 32 0.44, 64 0.9
   //   wider, and pattern-only W (every value 1) above 128-byte tile rows: the SELL kernel of stage 2, which re-streams only
   //                                   the 2-byte indices (B = 64: 0.61 vs 0.82 ms); column-major operands always
   // SS_COL=0: no 2-D kernel (SELL instead); SS_COL_FROM: its first B, pattern-only wide cases included (comparisons, tests)
