@@ -556,7 +556,11 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
       sidx[base] = (unsigned short)(idx[e] - k0);
       if (sval) sval[base] = val[e];
     } else {
-      sidx[base] = (unsigned short)KC;
+      // padding: one of the 16 zero rows behind the tile (KC .. KC+15, spmm_sell_kernel), the one whose 16-byte slot no
+      // active lane of this LDS cycle reads (the lowest free one; padding lanes of a group share it: same address)
+      int q = 0;
+      while (q < 15 && ((claimed >> q) & 1u)) ++q;
+      sidx[base] = (unsigned short)(KC + ((q - KC) & 15));
       if (sval) sval[base] = T(0);
     }
   }
@@ -597,7 +601,7 @@ __global__ void vrow_place_kernel(const int* __restrict__ perm, const int* __res
 template <class T>
 int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
   hipStream_t st = ctx().stream;
-  if (KCmax < 1 || KCmax > 65535) return fail(SS_EINVAL, "SELL chunk size out of range");
+  if (KCmax < 1 || KCmax > 65520) return fail(SS_EINVAL, "SELL chunk size out of range");   // local indices KC .. KC+15 are the zero rows
   out.rows = in.rows;
   out.cols = in.cols;
   out.binary = in.binary;

@@ -1306,6 +1306,7 @@ struct SellArgs {
 
 constexpr int SELL_THREADS = 1024;
 constexpr int SELL_NB = 4;  // quads of W in flight per lane ahead of the gathers
+constexpr int SELL_ZERO_ROWS = 16;  // zero rows behind the tile: one per 16-byte slot class of the 256-byte LDS line
 constexpr int SELL_STAGE_IT = 5;  // passes of SELL_THREADS per staging round (the largest tile, 10240 rows, takes two rounds)
 
 // Workgroup = QT columns of R (QT queries).  Per chunk of KC columns of W: the tile
@@ -1330,7 +1331,9 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
   static_assert(sizeof(Vec<T, QT>) == 16, "tile row must be 16 bytes");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   using V = Vec<T, QT>;
-  V* tile = reinterpret_cast<V*>(smem_raw);  // [KC + 1]; entry KC stays zero (padding target)
+  // [KC + 16]: rows KC .. KC+15 stay zero -- one padding target per 16-byte slot class, so that the builder can point a
+  // padding entry at a zero row whose slot no active lane of its LDS cycle uses (sell_fill_sched_kernel, assemble.hip)
+  V* tile = reinterpret_cast<V*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int64_t b0 = (int64_t)blockIdx.x * QT;
   // (the gathers below use tile-relative LDS addresses: the dynamic LDS segment must start at LDS address 0, i.e. the
@@ -1343,7 +1346,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
     // Stage the tile in rounds of SELL_STAGE_IT passes of 1024 threads: all loads of a round are requested before its
     // first LDS write (clamped, branch-free addresses) -- one memory latency per round (two for the largest tile)
     // instead of one per pass.  Nothing else runs on the CU meanwhile (one workgroup per CU): this latency is not hidden.
-    for (int kb = 0; kb <= a.KC; kb += SELL_STAGE_IT * SELL_THREADS) {
+    for (int kb = 0; kb < a.KC + SELL_ZERO_ROWS; kb += SELL_STAGE_IT * SELL_THREADS) {
       T stg[SELL_STAGE_IT][QT];
       const int klast = kn > 0 ? kn - 1 : 0;
 #pragma unroll
@@ -1359,7 +1362,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
 #pragma unroll
       for (int it = 0; it < SELL_STAGE_IT; ++it) {
         const int k = kb + tid + it * SELL_THREADS;
-        if (k <= a.KC) {
+        if (k < a.KC + SELL_ZERO_ROWS) {
           V v;
 #pragma unroll
           for (int q = 0; q < QT; ++q) v.v[q] = (k < kn && b0 + q < a.B) ? stg[it][q] : T(0);
@@ -1471,9 +1474,9 @@ template <> int sell_tile_width<double>() { return 2; }
 
 template <class T>
 int sell_max_chunk(int qt) {
-  // (KC + 1) * qt * sizeof(T) <= 160 KiB and KC <= 65535 (16-bit local index, KC is the sentinel)
-  int64_t kc = (int64_t)(160 * 1024) / ((int64_t)qt * (int64_t)sizeof(T)) - 1;
-  if (kc > 65535) kc = 65535;
+  // (KC + 16) * qt * sizeof(T) <= 160 KiB and KC + 15 <= 65535 (16-bit local indices; KC .. KC+15 are the zero rows)
+  int64_t kc = (int64_t)(160 * 1024) / ((int64_t)qt * (int64_t)sizeof(T)) - SELL_ZERO_ROWS;
+  if (kc > 65535 - (SELL_ZERO_ROWS - 1)) kc = 65535 - (SELL_ZERO_ROWS - 1);
   return (int)kc;
 }
 
@@ -1499,7 +1502,7 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
   a.ldf = ldf;
   a.clean_deg = clean_deg;
   a.out_rows = out_rows;
-  const size_t lds = (size_t)(W.KC + 1) * QT * sizeof(T);
+  const size_t lds = (size_t)(W.KC + SELL_ZERO_ROWS) * QT * sizeof(T);
   const unsigned gx = (unsigned)ceil_div(B, QT);
   unsigned gy = 1;
   if ((int)gx < 2 * ctx().num_cu) {
