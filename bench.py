@@ -128,7 +128,7 @@ def spmm_sweep(ss, torch, steps=5):
     lib.ss_spmat_destroy(h)
     return {"workload": f"W 100k x 100k, 1 percent dense (nnz {nnz}), fp32, CSR streamed once from HBM",
             "frac_hbm": "algorithmic bytes (CSR 8 B/nnz + R + F) / time / 8 TB/s",
-            "frac_hbm_streamed": "bytes of the chunk-major operand the kernels read (6 B/nnz + R + F) / time / 8 TB/s",
+            "frac_hbm_streamed": "bytes of the operand the kernels read (6 B/nnz: 2-byte local index + 4-byte value; the compact sliced-ELL operand of B >= 5 adds 0.2-0.6 B/nnz of pair padding and descriptors) + R + F) / time / 8 TB/s",
             "frac_hbm_achievable": "algorithmic bytes / time / 6.3 TB/s (the achievable rate MI355X_MICROARCH.md quotes; SURVEY.md 8d)",
             "results": out}
 

@@ -63,6 +63,9 @@ typedef struct ss_spmat ss_spmat; /* one sparse operand W of F = W*R, device res
 
 /* ---------------------------------------------------------------- runtime ---- */
 int ss_version(void);
+/* Hash of the kernel sources (csrc/*.hip, *.hpp) this library was built from -- what profiles/ records next to its
+ * counters; a loader that sees the sources can tell a stale library from a current one. */
+const char* ss_source_hash(void);
 const char* ss_last_error(void);
 int ss_device_count(void);
 /* Select the GPU this process drives and create the library's stream.  Replaces the
@@ -83,7 +86,7 @@ int ss_synchronize(void);
 int ss_timing_last(double* ms, int n);
 /* Which kernels the last predict / spmm call of this host thread went through: a comma-separated list of tags
  * ("transfer", "transfer_loo", "transfer_dense_bf16_ring", "transfer_dense_bf16_128", "transfer_dense_f32_mfma",
- * "spmm_sell", "spmm_sell_sorted", "spmm_colgroup", "spmm_chunked_narrow", ...), NUL-terminated, truncated
+ * "spmm_sell", "spmm_sell_sorted", "spmm_csell", "spmm_colgroup", "spmm_chunked_narrow", ...), NUL-terminated, truncated
  * to n - 1 characters.  Lets a caller (and the parity tests) assert that a size-dependent routing decision was the one
  * expected.  Has no counterpart in the reference (its only switch is GPU::Bool, src/core.jl:402,404). */
 int ss_path_last(char* buf, int n);

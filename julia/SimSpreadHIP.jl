@@ -29,6 +29,7 @@ end
 # ------------------------------------------------------------------------------------------------ runtime
 version() = ccall((:ss_version, LIB), Cint, ())
 last_error() = unsafe_string(ccall((:ss_last_error, LIB), Cstring, ()))
+source_hash() = unsafe_string(ccall((:ss_source_hash, LIB), Cstring, ()))
 device_count() = ccall((:ss_device_count, LIB), Cint, ())
 
 function check(rc::Cint)

@@ -39,6 +39,7 @@ def _sigs():
     f32, f64 = C.c_float, C.c_double
     s = {
         "ss_version": ([], _int),
+        "ss_source_hash": ([], C.c_char_p),
         "ss_last_error": ([], C.c_char_p),
         "ss_device_count": ([], _int),
         "ss_init": ([_int], _int),
@@ -106,6 +107,14 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
+    # a library older than the sources next to it must not run silently (its results and profiles would be credited to
+    # kernels that did not produce them)
+    if os.path.isdir(os.path.join(_HERE, "csrc")) and os.environ.get("SS_ALLOW_STALE_LIB") != "1":
+        built = lib.ss_source_hash().decode()
+        have = source_hash()
+        if built != have:
+            raise ImportError(f"{LIB_PATH} was built from other kernel sources ({built}) than the ones in csrc/ ({have}): "
+                              "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

@@ -97,3 +97,17 @@ def test_no_device_side_abort_in_any_kernel_source():
                     if re.search(r"__builtin_trap|\babort\s*\(|\bassert\s*\(|__assert_fail|std::terminate|\bthrow\b", code):
                         bad.append(f"{f}:{ln}: {line.strip()}")
     assert not bad, bad
+
+
+def test_library_reports_the_sources_it_was_built_from_and_a_stale_one_is_refused(monkeypatch):
+    """ss_source_hash() (csrc/build_id.cpp, value passed by the Makefile) must equal the hash of the sources next to the
+    library; the loader refuses a library built from other sources instead of running it silently."""
+    from simspread_jl_amd import _lib
+    lib = _lib.load()
+    assert lib.ss_source_hash().decode() == _lib.source_hash()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_hash", lambda: "0" * 12)
+    with pytest.raises(ImportError, match="other kernel sources"):
+        _lib.load()
+    monkeypatch.setenv("SS_ALLOW_STALE_LIB", "1")
+    assert _lib.load() is not None
