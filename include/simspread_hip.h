@@ -63,7 +63,7 @@ typedef struct ss_spmat ss_spmat; /* one sparse operand W of F = W*R, device res
 
 /* ---------------------------------------------------------------- runtime ---- */
 int ss_version(void);
-/* Hash of the kernel sources (csrc/*.hip, *.hpp) this library was built from -- what profiles/ records next to its
+/* Hash of the kernel sources (the .hip and .hpp files of csrc/) this library was built from -- what profiles/ records next to its
  * counters; a loader that sees the sources can tell a stale library from a current one. */
 const char* ss_source_hash(void);
 const char* ss_last_error(void);

@@ -11,7 +11,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimspread_hip.so")
+LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_HERE, "libsimspread_hip.so")   # SS_LIB_PATH: A/B builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "simspread_hip.h")
 
 SS_OK = 0

@@ -491,7 +491,10 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
                                                              int nslices, int nchunks, const int* __restrict__ off,
                                                              const int* __restrict__ vs, const int* __restrict__ ve,
                                                              int* __restrict__ perm, unsigned short* __restrict__ sidx,
-                                                             T* __restrict__ sval) {
+                                                             T* __restrict__ sval, int ncls, int npid) {
+  // ncls slot classes (tile rows per 256-byte LDS line: 16 for 16-byte rows, 8 for 32-byte rows), npid pieces per tile
+  // row: a lane reads piece r ^ (lane & (npid - 1)) in read r, so only lanes with the same lane & (npid - 1) compete for
+  // a class (claim bit = pid * ncls + class)
   __shared__ unsigned short cnt[64][17];
   __shared__ int cur[64][17];
   const int lane = threadIdx.x;
@@ -510,22 +513,23 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
     n = a - first;
   }
   // bucket this row's entries by 16-byte slot
-  for (int q = 0; q < 16; ++q) cnt[lane][q] = 0;
-  for (int x = 0; x < n; ++x) cnt[lane][(idx[first + x] - k0) & 15]++;
+  for (int q = 0; q < ncls; ++q) cnt[lane][q] = 0;
+  for (int x = 0; x < n; ++x) cnt[lane][(idx[first + x] - k0) & (ncls - 1)]++;
   int run = first;
-  for (int q = 0; q < 16; ++q) { cur[lane][q] = run; run += cnt[lane][q]; }
+  for (int q = 0; q < ncls; ++q) { cur[lane][q] = run; run += cnt[lane][q]; }
   for (int x = 0; x < n; ++x) {
-    const int q = (int)((idx[first + x] - k0) & 15);
+    const int q = (int)((idx[first + x] - k0) & (ncls - 1));
     perm[cur[lane][q]++] = first + x;
   }
-  for (int q = 0; q < 16; ++q) cur[lane][q] -= cnt[lane][q];
+  for (int q = 0; q < ncls; ++q) cur[lane][q] -= cnt[lane][q];
 
   int grp, gi;
   b128_group_of_lane(lane, grp, gi);
   const int o = off[wave], oe = off[wave + 1];
   int left = n;
   unsigned have = 0;   // slots this row still has entries in
-  for (int q = 0; q < 16; ++q) have |= (cnt[lane][q] > 0 ? 1u : 0u) << q;
+  for (int q = 0; q < ncls; ++q) have |= (cnt[lane][q] > 0 ? 1u : 0u) << q;
+  const int psh = (lane & (npid - 1)) * ncls;   // where this lane's claim bits start
   // Per position the 16 rows of a group pick their slots MOST CONSTRAINED FIRST (round 3; before: rotating priority): the
   // row with the fewest slots that are still free picks next (ties: the longer rest), and takes the free slot it has the
   // most entries in.  On Poisson(100) rows this leaves 1.10 LDS cycles per group and position instead of 1.23 (simulated;
@@ -537,7 +541,7 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
     for (int it = 0; it < 16; ++it) {
       if (__ballot(!done) == 0ull) break;
       const int rest = left > 4095 ? 4095 : left;
-      int key = done ? 0x7fffffff : ((__popc(have & ~claimed) << 20) | ((4095 - rest) << 4) | gi);
+      int key = done ? 0x7fffffff : ((__popc(have & ~(claimed >> psh)) << 20) | ((4095 - rest) << 4) | gi);
 #pragma unroll
       for (int m2 = 1; m2 < 16; m2 <<= 1) {
         const int other = __shfl(key, b128_lane_of_group(grp, gi ^ m2));
@@ -548,12 +552,12 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
       int choice = -1;
       if (any && !done && gi == wgi) {
         int best = -1, bestc = 0;
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < ncls; ++q) {
           const int cq = cnt[lane][q];
-          if (cq > bestc && !((claimed >> q) & 1u)) { best = q; bestc = cq; }
+          if (cq > bestc && !((claimed >> (psh + q)) & 1u)) { best = q; bestc = cq; }
         }
         if (best < 0)
-          for (int q = 0; q < 16; ++q) {
+          for (int q = 0; q < ncls; ++q) {
             const int cq = cnt[lane][q];
             if (cq > bestc) { best = q; bestc = cq; }
           }
@@ -561,8 +565,9 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
         mine = best;
         done = true;
       }
-      const int ch = __shfl(choice, b128_lane_of_group(grp, wgi));
-      if (any && ch >= 0) claimed |= 1u << ch;
+      const int wl = b128_lane_of_group(grp, wgi);
+      const int ch = __shfl(choice, wl);
+      if (any && ch >= 0) claimed |= 1u << ((wl & (npid - 1)) * ncls + ch);
     }
     const int64_t base = ((int64_t)(o + (p >> 2)) * 64 + lane) * 4 + (p & 3);
     if (mine >= 0) {
@@ -577,8 +582,8 @@ __global__ void __launch_bounds__(64) sell_fill_sched_kernel(const int* __restri
       // padding: one of the 16 zero rows behind the tile (KC .. KC+15, spmm_sell_kernel), the one whose 16-byte slot no
       // active lane of this LDS cycle reads (the lowest free one; padding lanes of a group share it: same address)
       int q = 0;
-      while (q < 15 && ((claimed >> q) & 1u)) ++q;
-      sidx[base] = (unsigned short)(KC + ((q - KC) & 15));
+      while (q < ncls - 1 && ((claimed >> (psh + q)) & 1u)) ++q;
+      sidx[base] = (unsigned short)(KC + ((q - KC) & (ncls - 1)));
       if (sval) sval[base] = T(0);
     }
   }
@@ -617,8 +622,13 @@ __global__ void vrow_place_kernel(const int* __restrict__ perm, const int* __res
 }
 
 template <class T>
-int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
+int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out, int qt) {
   hipStream_t st = ctx().stream;
+  if (qt <= 0) qt = sell_tile_width<T>();
+  const int rowb = qt * (int)sizeof(T);
+  if (rowb != 16 && rowb != 32) return fail(SS_EINVAL, "SELL tile rows must be 16 or 32 bytes");
+  out.qt = qt;
+  const int ncls = 256 / rowb, npid = rowb / 16;
   if (KCmax < 1 || KCmax > 65520) return fail(SS_EINVAL, "SELL chunk size out of range");   // local indices KC .. KC+15 are the zero rows
   out.rows = in.rows;
   out.cols = in.cols;
@@ -725,7 +735,7 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out) {
                        out.vrows, out.KC, out.nslices, out.nchunks, out.off.p,
                        out.sorted ? (const int*)out.vs.p : (const int*)nullptr,
                        out.sorted ? (const int*)out.ve.p : (const int*)nullptr, perm.p, out.idx.p,
-                       out.binary ? (T*)nullptr : out.val.p);
+                       out.binary ? (T*)nullptr : out.val.p, ncls, npid);
     SS_LAUNCH_CHECK();
     SS_HIP(hipStreamSynchronize(st));
   }
@@ -1216,7 +1226,7 @@ int graph_finalize_general_targets(Graph<T>& g) {
   template int csr_from_dense<T>(const T*, int64_t, int64_t, int64_t, bool, T, bool, int, DevCsr<T>&);         \
   template int csr_transpose<T>(const DevCsr<T>&, DevCsr<T>&);                                                 \
   template int chunked_build<T>(const DevCsr<T>&, int, int, DevChunked<T>&);                                     \
-  template int sell_build<T>(const DevCsr<T>&, int, DevSell<T>&);                                              \
+  template int sell_build<T>(const DevCsr<T>&, int, DevSell<T>&, int);                                            \
   template int graph_finalize<T>(Graph<T>&);                                                                   \
   template int graph_finalize_general<T>(Graph<T>&);
 SS_INSTANTIATE(float)

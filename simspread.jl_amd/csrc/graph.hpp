@@ -23,7 +23,8 @@ struct DevCsr {
 template <class T>
 struct DevSell {
   int64_t rows = 0, cols = 0;
-  int KC = 0;          // columns per chunk (<= 65535); local index KC is the zero sentinel
+  int KC = 0;          // columns per chunk; local indices KC .. KC+15 are zero rows (padding targets)
+  int qt = 0;          // columns per tile row the entry order was scheduled for (slot classes = 256 / (qt * sizeof(T)))
   int nchunks = 0;
   int nslices = 0;     // ceil(rows / 64)
   int64_t nquads = 0;  // total storage in units of 64 lanes x 4 entries
@@ -143,7 +144,7 @@ int csr_from_dense(const T* S, int64_t rows, int64_t cols, int64_t ld, bool appl
 template <class T>
 int csr_transpose(const DevCsr<T>& in, DevCsr<T>& out);
 template <class T>
-int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out);
+int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out, int qt = 0);   // qt = 0: sell_tile_width<T>()
 template <class T>
 int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out);
 int csell_build(const DevCsr<float>& in, int KC, int QT, DevCsell& out);   // out.ok == false: not representable (no error)

@@ -1306,6 +1306,7 @@ struct SellArgs {
 
 constexpr int SELL_THREADS = 1024;
 constexpr int SELL_NB = 4;  // quads of W in flight per lane ahead of the gathers
+constexpr int SELL_QT_F32_DEFAULT = 4;
 constexpr int SELL_ZERO_ROWS = 16;  // zero rows behind the tile: one per 16-byte slot class of the 256-byte LDS line
 constexpr int SELL_STAGE_IT = 5;  // passes of SELL_THREADS per staging round (the largest tile, 10240 rows, takes two rounds)
 
@@ -1327,8 +1328,18 @@ __device__ __forceinline__ unsigned half_shl(unsigned x, unsigned sh) {
 
 template <class T, int QT, bool BIN>
 __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) {
-  constexpr unsigned TSH = 4;  // log2(sizeof(Vec<T,QT>)): 16-byte tile rows for (float,4) and (double,2)
-  static_assert(sizeof(Vec<T, QT>) == 16, "tile row must be 16 bytes");
+  // Tile rows of 16 bytes ((float,4), (double,2)), or of 32 bytes = two 16-byte pieces ((float,8), round 3): the index
+  // stream of W, which every workgroup re-reads for its own columns, is then shared by twice as many columns.  It is what
+  // bounds this kernel (measured by ablation: without it stage 2 takes 0.36 instead of 0.59 ms at C2, 7.4 instead of
+  // 12.7 ms at C3; with half the LDS reads 0.55 / 12.1).  With two pieces a lane reads piece r ^ (lane & 1) in read r, so
+  // that the 16 lanes of an LDS cycle are spread over 16 (slot class, piece) cells; the accumulators hold the columns in
+  // that rotated order and are put back when they are stored.
+  constexpr int RB = (int)sizeof(T) * QT, NP = RB / 16;
+  // registers: two-piece rows stage fewer passes per round and (weighted) keep fewer quads in flight
+  constexpr int STAGE_IT = NP == 2 ? 2 : SELL_STAGE_IT;
+  constexpr int NBQ = NP == 2 ? 2 : SELL_NB;   // divides SELL_NB: the builder pads slices to groups of SELL_NB quads
+  constexpr unsigned TSH = NP == 2 ? 5 : 4;  // log2(RB)
+  static_assert(RB == 16 || (RB == 32 && sizeof(T) == 4), "tile row must be 16 bytes, or 32 bytes of fp32");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   using V = Vec<T, QT>;
   // [KC + 16]: rows KC .. KC+15 stay zero -- one padding target per 16-byte slot class, so that the builder can point a
@@ -1336,6 +1347,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
   V* tile = reinterpret_cast<V*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int64_t b0 = (int64_t)blockIdx.x * QT;
+  const unsigned pid = NP == 2 ? (unsigned)(lane & 1) : 0u;   // which piece this lane reads first
   // (the gathers below use tile-relative LDS addresses: the dynamic LDS segment must start at LDS address 0, i.e. the
   // kernel must have no static __shared__ object -- launch_spmm_sell checks that on the host before the first launch)
 
@@ -1346,11 +1358,11 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
     // Stage the tile in rounds of SELL_STAGE_IT passes of 1024 threads: all loads of a round are requested before its
     // first LDS write (clamped, branch-free addresses) -- one memory latency per round (two for the largest tile)
     // instead of one per pass.  Nothing else runs on the CU meanwhile (one workgroup per CU): this latency is not hidden.
-    for (int kb = 0; kb < a.KC + SELL_ZERO_ROWS; kb += SELL_STAGE_IT * SELL_THREADS) {
-      T stg[SELL_STAGE_IT][QT];
+    for (int kb = 0; kb < a.KC + SELL_ZERO_ROWS; kb += STAGE_IT * SELL_THREADS) {
+      T stg[STAGE_IT][QT];
       const int klast = kn > 0 ? kn - 1 : 0;
 #pragma unroll
-      for (int it = 0; it < SELL_STAGE_IT; ++it) {
+      for (int it = 0; it < STAGE_IT; ++it) {
         const int k = kb + tid + it * SELL_THREADS;
         const int kk = k < kn ? k : klast;
 #pragma unroll
@@ -1360,7 +1372,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
         }
       }
 #pragma unroll
-      for (int it = 0; it < SELL_STAGE_IT; ++it) {
+      for (int it = 0; it < STAGE_IT; ++it) {
         const int k = kb + tid + it * SELL_THREADS;
         if (k < a.KC + SELL_ZERO_ROWS) {
           V v;
@@ -1388,7 +1400,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
 #pragma unroll
       for (int q = 0; q < QT; ++q) {
         fprev[q] = T(0);
-        if (c && m < a.M && b0 + q < a.B)
+        if (NP == 1 && c && m < a.M && b0 + q < a.B)   // (two-piece rows: read when the slice is done -- registers)
           fprev[q] = a.F[(a.out_rows ? (int64_t)a.out_rows[b0 + q] : b0 + q) * a.ldf + m];
       }
       const ushort4* ip = reinterpret_cast<const ushort4*>(a.idx) + (int64_t)o * 64 + lane;
@@ -1401,30 +1413,40 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
       // past the end of a slice is loaded and never used.  Two register sets (A/B) alternate, nothing is copied.
       const uint2* ipw = reinterpret_cast<const uint2*>(ip);
       const int nq = oe - o;
-      uint2 ia[SELL_NB], ib[SELL_NB];
-      Vec<T, 4> wa[SELL_NB], wb[SELL_NB];
-      auto fetch = [&](uint2 (&iq)[SELL_NB], Vec<T, 4> (&wq)[SELL_NB], int base) __attribute__((always_inline)) {
+      uint2 ia[NBQ], ib[NBQ];
+      Vec<T, 4> wa[NBQ], wb[NBQ];
+      auto fetch = [&](uint2 (&iq)[NBQ], Vec<T, 4> (&wq)[NBQ], int base) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < SELL_NB; ++j) {
+        for (int j = 0; j < NBQ; ++j) {
           iq[j] = ipw[(int64_t)(base + j) * 64];
           if (!BIN) wq[j] = vp[(int64_t)(base + j) * 64];
         }
       };
-      auto gather = [&](const uint2 (&iq)[SELL_NB], const Vec<T, 4> (&wq)[SELL_NB]) __attribute__((always_inline)) {
+      auto gather = [&](const uint2 (&iq)[NBQ], const Vec<T, 4> (&wq)[NBQ]) __attribute__((always_inline)) {
         // LDS address of tile[k] = k * 16: one SDWA shift per 16-bit index, used as the address itself (the tile
         // is the only LDS object of this kernel and starts at LDS address 0 -- checked once at kernel entry;
         // going through the generic tile pointer costs one more VALU add per non-zero)
-        typedef T NV __attribute__((ext_vector_type(QT)));
+        constexpr int PV = 16 / (int)sizeof(T);   // values per 16-byte piece
+        typedef T NV __attribute__((ext_vector_type(PV)));
         using LV = const __attribute__((address_space(3))) NV*;
-        auto row = [](unsigned addr) __attribute__((always_inline)) {
-          const NV n = *(LV)(uintptr_t)addr;
+        const unsigned lb = pid << 4;
+        auto row = [&](unsigned addr) __attribute__((always_inline)) {
           V r;
+          if (NP == 1) {
+            const NV n = *(LV)(uintptr_t)addr;
 #pragma unroll
-          for (int q = 0; q < QT; ++q) r.v[q] = n[q];
+            for (int q = 0; q < PV; ++q) r.v[q] = n[q];
+          } else {
+            const unsigned a0 = addr | lb;
+            const NV n0 = *(LV)(uintptr_t)a0;
+            const NV n1 = *(LV)(uintptr_t)(a0 ^ 16u);
+#pragma unroll
+            for (int q = 0; q < PV; ++q) { r.v[q] = n0[q]; r.v[PV + q] = n1[q]; }
+          }
           return r;
         };
 #pragma unroll
-        for (int j = 0; j < SELL_NB; ++j) {
+        for (int j = 0; j < NBQ; ++j) {
           const V t0 = row(half_shl<0>(iq[j].x, TSH));
           const V t1 = row(half_shl<1>(iq[j].x, TSH));
           const V t2 = row(half_shl<0>(iq[j].y, TSH));
@@ -1441,16 +1463,21 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
               acc[q] = fma(wq[j].v[3], t3.v[q], acc[q]);
             }
           }
+          // two-piece rows: one quad's eight reads at a time (all of a group's at once would need 128 registers)
+          if (NP == 2) __builtin_amdgcn_sched_barrier(0);
         }
       };
       // (both gathers of the loop body are unconditional on purpose: a gather under `if` lets the compiler sink
       // its loads into the branch, right in front of their use)
+      // Measured and not kept (round 3): a third register set (two groups of quads in flight while one is gathered; the
+      // gathers split in two by a compiler barrier so that it fits in 123 registers): 0.605 vs 0.594 ms at C2, 12.8 vs
+      // 12.6 ms at C3 -- the index stream is bound by the bytes through the CU's vector-memory path, not by its latency.
       fetch(ia, wa, 0);
       int u = 0;
-      for (; u + 2 * SELL_NB <= nq; u += 2 * SELL_NB) {
-        fetch(ib, wb, u + SELL_NB);
+      for (; u + 2 * NBQ <= nq; u += 2 * NBQ) {
+        fetch(ib, wb, u + NBQ);
         gather(ia, wa);
-        fetch(ia, wa, u + 2 * SELL_NB);
+        fetch(ia, wa, u + 2 * NBQ);
         gather(ib, wb);
       }
       if (u < nq) gather(ia, wa);  // odd number of groups: the last one is already here
@@ -1460,7 +1487,9 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
         for (int q = 0; q < QT; ++q) {
           if (b0 + q < a.B) {
             T* f = a.F + (a.out_rows ? (int64_t)a.out_rows[b0 + q] : b0 + q) * a.ldf + m;
-            const T r = acc[q] + fprev[q];
+            // two-piece rows: odd lanes read the pieces in the order 1, 0 -- their accumulators q and q ^ 4 are swapped
+            const T mine = NP == 2 ? (pid ? acc[q ^ (QT / 2)] : acc[q]) : acc[q];
+            const T r = mine + ((NP == 2 && c) ? *f : fprev[q]);
             *f = flag ? T(-99) : r;
           }
         }
@@ -1469,7 +1498,14 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
   }
 }
 
-template <> int sell_tile_width<float>() { return 4; }
+// fp32: 8 columns per tile row since round 3 (SS_SELL_QT=4: the 16-byte rows of rounds 1-2)
+template <> int sell_tile_width<float>() {
+  if (const char* e = getenv("SS_SELL_QT")) {
+    const int v = atoi(e);
+    if (v == 4 || v == 8) return v;
+  }
+  return SELL_QT_F32_DEFAULT;
+}
 template <> int sell_tile_width<double>() { return 2; }
 
 template <class T>
@@ -1485,7 +1521,7 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
                      const int* clean_deg, const int* out_rows) {
   if (B <= 0 || W.rows <= 0) return SS_OK;
   path_add(W.sorted ? "spmm_sell_sorted" : "spmm_sell");
-  constexpr int QT = sizeof(T) == 4 ? 4 : 2;
+  const int QT = W.qt > 0 ? W.qt : (sizeof(T) == 4 ? 4 : 2);
   SellArgs<T> a{};
   a.off = W.off.p;
   a.idx = W.idx.p;
@@ -1503,6 +1539,7 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
   a.clean_deg = clean_deg;
   a.out_rows = out_rows;
   const size_t lds = (size_t)(W.KC + SELL_ZERO_ROWS) * QT * sizeof(T);
+  if (lds > (size_t)160 * 1024) return fail(SS_EINVAL, "SELL chunk does not fit the LDS tile of %d columns", QT);
   const unsigned gx = (unsigned)ceil_div(B, QT);
   unsigned gy = 1;
   if ((int)gx < 2 * ctx().num_cu) {
@@ -1511,7 +1548,6 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
     if (gy > maxy) gy = maxy > 0 ? maxy : 1;
   }
   const dim3 grid(gx, gy);
-  static std::atomic<bool> attr_set[2] = {{false}, {false}};
   // first launch of an instantiation: raise its dynamic-LDS limit and check, on the host, what the kernel's LDS
   // addressing relies on -- no static LDS in the code object's kernel, so that the dynamic segment starts at 0.
   // (A violated assumption is an error code for the caller, never a device-side abort.)
@@ -1524,19 +1560,24 @@ int launch_spmm_sell(const DevSell<T>& W, const T* R, int64_t ldr, int64_t B, T*
     SS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return SS_OK;
   };
-  if (W.binary) {
-    if (!attr_set[0]) {
-      SS_TRY(prepare(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, true>)));
-      attr_set[0] = true;
-    }
-    hipLaunchKernelGGL((spmm_sell_kernel<T, QT, true>), grid, dim3(SELL_THREADS), lds, ctx().stream, a);
+#define SS_SELL_LAUNCH(QTV, BINV, SLOT)                                                                      \
+  do {                                                                                                       \
+    static std::atomic<bool> attr_done{false};                                                               \
+    if (!attr_done) {                                                                                        \
+      SS_TRY(prepare(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QTV, BINV>)));                       \
+      attr_done = true;                                                                                      \
+    }                                                                                                        \
+    hipLaunchKernelGGL((spmm_sell_kernel<T, QTV, BINV>), grid, dim3(SELL_THREADS), lds, ctx().stream, a);    \
+  } while (0)
+  if constexpr (sizeof(T) == 4) {
+    if (QT == 8) { if (W.binary) SS_SELL_LAUNCH(8, true, 0); else SS_SELL_LAUNCH(8, false, 1); }
+    else if (QT == 4) { if (W.binary) SS_SELL_LAUNCH(4, true, 2); else SS_SELL_LAUNCH(4, false, 3); }
+    else return fail(SS_EINVAL, "SELL tile width must be 4 or 8 (fp32)");
   } else {
-    if (!attr_set[1]) {
-      SS_TRY(prepare(reinterpret_cast<const void*>(&spmm_sell_kernel<T, QT, false>)));
-      attr_set[1] = true;
-    }
-    hipLaunchKernelGGL((spmm_sell_kernel<T, QT, false>), grid, dim3(SELL_THREADS), lds, ctx().stream, a);
+    if (QT != 2) return fail(SS_EINVAL, "SELL tile width must be 2 (fp64)");
+    if (W.binary) SS_SELL_LAUNCH(2, true, 0); else SS_SELL_LAUNCH(2, false, 1);
   }
+#undef SS_SELL_LAUNCH
   SS_LAUNCH_CHECK();
   return SS_OK;
 }

@@ -667,6 +667,29 @@ def test_spmm_width_routing(dtype, B, monkeypatch):
     assert any("spmm_sell" in k for k in ss.path_last())
 
 
+@pytest.mark.parametrize("weighted_y", [False, True])
+def test_stage2_two_piece_tile_rows_variant(weighted_y, monkeypatch):
+    """SS_SELL_QT=8 (opt-in): 32-byte tile rows = two 16-byte pieces per tile row, eight slot classes, the
+    lanes of an LDS cycle split by the piece they read first, accumulators un-rotated at the store.  Several chunks
+    (F is added to chunk by chunk), a query count that is no multiple of 8, an empty target for clean!."""
+    Xq, Xs, Ys = O.synth_bipartite(203, 1500, 1500, 700, 0.05, 0.03, seed=77, dtype=np.float32)
+    Ys = Ys.tolil(); Ys[:, 9] = 0; Ys = Ys.tocsr()
+    if weighted_y:
+        Ys.data = (0.5 + np.random.default_rng(3).random(Ys.nnz)).astype(np.float32)
+    f64 = [m.astype(np.float64) for m in (Xq, Xs, Ys)]
+    want = O.predict_factored(*f64)
+    want[:, 9] = -99.0
+    monkeypatch.setenv("SS_SELL_QT", "8")
+    for chunk in (None, "400"):
+        if chunk:
+            monkeypatch.setenv("SS_SELL_CHUNK", chunk)
+        g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+        got = g.predict("query", clean=True)
+        assert_close(np.where(want == -99, 0, got), np.where(want == -99, 0, want), np.float32)
+        assert ((want == -99) == (got == -99)).all()
+        g.close()
+
+
 def test_power_law_graph_predict_with_sorted_split_operand(monkeypatch):
     rng = np.random.default_rng(12)
     ns, nt, nq = 600, 500, 77
