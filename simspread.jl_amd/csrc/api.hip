@@ -830,26 +830,24 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
     const int rowb = B * (int64_t)sizeof(T) <= 64 ? 64 : (B * (int64_t)sizeof(T) <= 128 ? 128 : 256);
     const int slot = rowb == 64 ? 0 : (rowb == 128 ? 1 : 2);
     const int bv = rowb / (int)sizeof(T);
-    // fp32: the lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip, round 3); SS_CSELL=0: the 2-D kernel
+    // the lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip, round 3); SS_CSELL=0: the 2-D kernel
     bool done = false;
-    if constexpr (sizeof(T) == 4) {
-      if (!(getenv("SS_CSELL") && atoi(getenv("SS_CSELL")) == 0)) {
-        DevCsell& cs = m.csell[slot];
-        if (!m.csell_tried[slot]) {
-          int kc = csell_chunk_cols(bv);
-          if (const char* e = getenv("SS_NARROW_CHUNK")) {
-            const int v = atoi(e);
-            if (v >= 16 && v < kc) kc = v;
-          }
-          SS_TRY(csell_build(m.csr, kc, bv, cs));
-          m.csell_tried[slot] = true;
+    if (!(getenv("SS_CSELL") && atoi(getenv("SS_CSELL")) == 0)) {
+      DevCsell<T>& cs = m.csell[slot];
+      if (!m.csell_tried[slot]) {
+        int kc = csell_chunk_cols(rowb);
+        if (const char* e = getenv("SS_NARROW_CHUNK")) {
+          const int v = atoi(e);
+          if (v >= 16 && v < kc) kc = v;
         }
-        if (cs.ok) {
-          StageTimer t2(ST_SPMM);
-          SS_TRY(launch_spmm_csell(cs, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
-          timing_count(ST_NSPMM, 1);
-          done = true;
-        }
+        SS_TRY(csell_build<T>(m.csr, kc, bv, cs));
+        m.csell_tried[slot] = true;
+      }
+      if (cs.ok) {
+        StageTimer t2(ST_SPMM);
+        SS_TRY(launch_spmm_csell<T>(cs, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
+        timing_count(ST_NSPMM, 1);
+        done = true;
       }
     }
     DevChunked<T>& op = m.col[slot];

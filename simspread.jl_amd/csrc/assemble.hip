@@ -792,16 +792,16 @@ __global__ void csell_desc_kernel(const int* __restrict__ base, const int* __res
 }
 
 // One wave per block: writes the block's pairs in step order.  The order of a lane's entries is free; for tile rows
-// narrower than an LDS line (QT = 16, 32: 4 / 2 tile rows per 256 bytes) it is scheduled position by position: the lanes
-// that read the same 16-byte slot number in the same LDS cycle (same lane & (QT/4 - 1) inside one of the four 16-lane
+// narrower than an LDS line (64 / 128 bytes: 4 / 2 tile rows per 256 bytes) it is scheduled position by position: the lanes
+// that read the same 16-byte slot number in the same LDS cycle (same lane & (pieces - 1) inside one of the four 16-lane
 // groups ds_read_b128 is served in) take tile rows of different classes (k mod 4 / k mod 2), largest remaining class first,
 // rotating priority; a lane with nothing else left takes a conflicting entry.
-template <int QT>
+template <class T, int ROWB>
 __global__ void __launch_bounds__(64) csell_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
-                                                        const float* __restrict__ val, int64_t rows, int KC, int nslices,
+                                                        const T* __restrict__ val, int64_t rows, int KC, int nslices,
                                                         int64_t nblocks, const int* __restrict__ desc, int* __restrict__ perm,
-                                                        unsigned short* __restrict__ pidx16, float* __restrict__ pval) {
-  constexpr int NPC = QT / 4, NCL = 64 / QT;
+                                                        unsigned short* __restrict__ pidx16, T* __restrict__ pval) {
+  constexpr int NPC = ROWB / 16, NCL = 256 / ROWB;   // 16-byte pieces per tile row, tile rows per LDS line
   __shared__ unsigned short cnt[64][NCL + 1];
   __shared__ int cur[64][NCL + 1];
   const int lane = threadIdx.x;
@@ -875,17 +875,19 @@ __global__ void __launch_bounds__(64) csell_fill_kernel(const int* __restrict__ 
       if (act) {
         const int64_t at = (base + runp + rank) * 2 + half;
         pidx16[at] = e >= 0 ? (unsigned short)(idx[e] - k0) : (unsigned short)KC;
-        if (pval) pval[at] = e >= 0 ? val[e] : 0.f;
+        if (pval) pval[at] = e >= 0 ? val[e] : T(0);
       }
       if (half == 1) runp += __builtin_popcountll(mask);
     }
   }
 }
 
-int csell_build(const DevCsr<float>& in, int KC, int QT, DevCsell& out) {
+template <class T>
+int csell_build(const DevCsr<T>& in, int KC, int QT, DevCsell<T>& out) {
   hipStream_t st = ctx().stream;
   if (KC < 1 || KC > 32767) return fail(SS_EINVAL, "compact sliced ELL: chunk size out of range");
-  if (QT != 16 && QT != 32 && QT != 64) return fail(SS_EINVAL, "compact sliced ELL: tile width must be 16, 32 or 64");
+  const int rowb = QT * (int)sizeof(T);
+  if (rowb != 64 && rowb != 128 && rowb != 256) return fail(SS_EINVAL, "compact sliced ELL: tile rows must be 64, 128 or 256 bytes");
   out.ok = false;
   out.rows = in.rows; out.cols = in.cols; out.nnz = in.nnz; out.binary = in.binary;
   out.KC = KC; out.QT = QT;
@@ -915,28 +917,30 @@ int csell_build(const DevCsr<float>& in, int KC, int QT, DevCsell& out) {
   SS_HIP(hipMemsetAsync(out.pidx.p + total, 0, 64 * sizeof(unsigned), st));
   if (!in.binary) {
     SS_TRY(out.pval.alloc(2 * ((size_t)total + 64)));
-    SS_HIP(hipMemsetAsync(out.pval.p + 2 * (size_t)total, 0, 128 * sizeof(float), st));
+    SS_HIP(hipMemsetAsync(out.pval.p + 2 * (size_t)total, 0, 128 * sizeof(T), st));
   } else {
     out.pval.release();
   }
   DevBuf<int> perm;
-  if (QT < 64) SS_TRY(perm.alloc(in.nnz));
+  if (rowb < 256) SS_TRY(perm.alloc(in.nnz));
   unsigned short* p16 = reinterpret_cast<unsigned short*>(out.pidx.p);
-  float* pv = in.binary ? (float*)nullptr : out.pval.p;
-  if (QT == 16)
-    hipLaunchKernelGGL(csell_fill_kernel<16>, dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
+  T* pv = in.binary ? (T*)nullptr : out.pval.p;
+  if (rowb == 64)
+    hipLaunchKernelGGL((csell_fill_kernel<T, 64>), dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
                        out.nslices, nblocks, out.desc.p, perm.p, p16, pv);
-  else if (QT == 32)
-    hipLaunchKernelGGL(csell_fill_kernel<32>, dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
+  else if (rowb == 128)
+    hipLaunchKernelGGL((csell_fill_kernel<T, 128>), dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
                        out.nslices, nblocks, out.desc.p, perm.p, p16, pv);
   else
-    hipLaunchKernelGGL(csell_fill_kernel<64>, dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
+    hipLaunchKernelGGL((csell_fill_kernel<T, 256>), dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
                        out.nslices, nblocks, out.desc.p, perm.p, p16, pv);
   SS_LAUNCH_CHECK();
   SS_HIP(hipStreamSynchronize(st));   // perm and the counters are freed on return
   out.ok = true;
   return SS_OK;
 }
+template int csell_build<float>(const DevCsr<float>&, int, int, DevCsell<float>&);
+template int csell_build<double>(const DevCsr<double>&, int, int, DevCsell<double>&);
 
 // largest and smallest non-zero |value| of an array, as fp32 bit patterns (non-negative floats order like integers)
 template <class T>

@@ -71,17 +71,18 @@ struct DevChunked {
 // holds no padding except the odd last entry of a sub-row (index KC = the zero row of the tile, value 0).  The order of
 // the entries inside a sub-row is chosen when the operand is built so that lanes which read the same 16-byte slot of an
 // LDS line in the same cycle hold tile rows of different bank classes (tile rows narrower than 256 bytes).
+template <class T>
 struct DevCsell {
   int64_t rows = 0, cols = 0, nnz = 0;
   int KC = 0, nchunks = 0, nslices = 0;
-  int QT = 0;                     // tile width (columns of R per tile row) the entry order was scheduled for: 16, 32, 64
+  int QT = 0;                     // tile width (columns of R per tile row) the entry order was scheduled for: QT * sizeof(T) = 64, 128 or 256 bytes
   bool binary = false;            // every value 1: no value stream
   bool ok = false;                // built (false: not yet, or the matrix does not fit the format -> the 2-D kernel serves it)
   int64_t npairs = 0;
   DevBuf<int> desc;               // [nblocks + 1][2] {first pair, steps}; the last block is empty
   DevBuf<unsigned short> np;      // [(nblocks + 1) * 64] pairs per lane
   DevBuf<unsigned> pidx;          // [npairs + 64]
-  DevBuf<float> pval;             // [2 * (npairs + 64)] unless binary
+  DevBuf<T> pval;                 // [2 * (npairs + 64)] unless binary
 };
 
 // Dense-similarity regime: the raw similarities stay dense on the device (column-major), the cutoff is
@@ -129,7 +130,7 @@ struct SpMat {
   int sell_qt = 0;
   DevChunked<T> narrow[3];  // quad-aligned chunked operands of the narrow kernel for B <= 1, 2, 4 (built lazily)
   DevChunked<T> col[3];     // operands of the 2-D kernel: 64-, 128- and 256-byte tile rows (built lazily)
-  DevCsell csell[3];        // fp32: operands of the lane-per-row kernel for 16, 32 and 64 columns (built lazily)
+  DevCsell<T> csell[3];     // operands of the lane-per-row kernel for 64-, 128- and 256-byte tile rows (built lazily)
   bool csell_tried[3] = {false, false, false};
   DevBuf<T> partial;        // partial sums of the narrow / 2-D kernels (and the padded copy of R, spmm_colgroup.hip)
 };
@@ -147,7 +148,8 @@ template <class T>
 int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out, int qt = 0);   // qt = 0: sell_tile_width<T>()
 template <class T>
 int chunked_build(const DevCsr<T>& in, int SC, int align, DevChunked<T>& out);
-int csell_build(const DevCsr<float>& in, int KC, int QT, DevCsell& out);   // out.ok == false: not representable (no error)
+template <class T>
+int csell_build(const DevCsr<T>& in, int KC, int QT, DevCsell<T>& out);   // out.ok == false: not representable (no error)
 template <class T>
 int graph_finalize(Graph<T>& g);  // transposes + degrees
 template <class T>
@@ -214,9 +216,10 @@ int launch_spmm_chunked_narrow(const DevChunked<T>& W, int bv, const T* R, int64
 // stage 2, mid width (5 <= B, B*sizeof(T) <= 256 bytes): 2-D cut (row blocks x chunk groups) with conflict-free gathers
 // (spmm_colgroup.hip): tile rows of 64, 128 or 256 bytes (fp32: B <= 16, 32, 64; fp64: B <= 8, 16, 32); same chunked
 // operand format as the narrow kernel
-// ---- spmm_csell.hip (fp32, 5 <= B <= 64, row-major R and F)
-int csell_chunk_cols(int qt);   // tile rows that fit in LDS next to the zero row
-int launch_spmm_csell(const DevCsell& W, const float* R, int64_t ldr, int B, float* F, int64_t ldf, DevBuf<float>& partial);
+// ---- spmm_csell.hip (5 <= B, B * sizeof(T) <= 256 bytes, row-major R and F)
+int csell_chunk_cols(int rowb);   // tile rows (of rowb bytes) that fit in LDS next to the zero row
+template <class T>
+int launch_spmm_csell(const DevCsell<T>& W, const T* R, int64_t ldr, int B, T* F, int64_t ldf, DevBuf<T>& partial);
 template <class T>
 int colgroup_chunk_cols(int bv);
 template <class T>

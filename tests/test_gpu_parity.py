@@ -578,9 +578,12 @@ def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
 
 
 @pytest.mark.parametrize("binary", [False, True])
-@pytest.mark.parametrize("B", [5, 12, 16, 17, 28, 32, 33, 52, 64])
-def test_spmm_csell_lane_per_row(B, binary, monkeypatch):
-    """fp32 mid width since round 3: the lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip,
+@pytest.mark.parametrize("B,dtype", [(5, np.float32), (12, np.float32), (16, np.float32), (17, np.float32), (28, np.float32),
+                                     (32, np.float32), (33, np.float32), (52, np.float32), (64, np.float32),
+                                     (5, np.float64), (8, np.float64), (9, np.float64), (16, np.float64), (23, np.float64),
+                                     (32, np.float64)])
+def test_spmm_csell_lane_per_row(B, dtype, binary, monkeypatch):
+    """Mid width since round 3 (fp32 B <= 64, fp64 B <= 32): the lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip,
     csell_build in assemble.hip).  Row count no multiple of 64, empty rows, a FULL row (a 500-entry sub-row in every
     chunk: 250 steps in a block whose other lanes have ~3), an odd-length tail in most sub-rows (pad entry -> zero tile
     row), 6 chunks of R, widths that need the padded copy of R and scalar stores (5, 17, 33), several cuts (slices per
@@ -605,20 +608,20 @@ def test_spmm_csell_lane_per_row(B, binary, monkeypatch):
     for cut in (None, "3,1", "7,2", "1,6", "16,1"):
         if cut:
             monkeypatch.setenv("SS_CSELL_CUT", cut)
-        w = ss.DeviceSpMat(W.astype(np.float32), dtype=np.float32)
-        got = w.spmm(R.astype(np.float32))
+        w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
+        got = w.spmm(R.astype(dtype))
         assert "spmm_csell" in ss.path_last(), ss.path_last()
-        assert_close_signed(got, want, np.float32)
-        assert np.array_equal(got, w.spmm(R.astype(np.float32)))
+        assert_close_signed(got, want, dtype)
+        assert np.array_equal(got, w.spmm(R.astype(dtype)))
         if cut and cut.endswith(",1"):
             one_group.append(got)
     assert np.array_equal(one_group[0], one_group[1])
     monkeypatch.delenv("SS_CSELL_CUT")
     monkeypatch.setenv("SS_CSELL", "0")
-    w0 = ss.DeviceSpMat(W.astype(np.float32), dtype=np.float32)
-    other = w0.spmm(R.astype(np.float32))
+    w0 = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
+    other = w0.spmm(R.astype(dtype))
     assert "spmm_colgroup" in ss.path_last()
-    assert_close_signed(other, want, np.float32)
+    assert_close_signed(other, want, dtype)
 
 
 def test_spmm_csell_tiny_and_degenerate_shapes():
@@ -641,7 +644,7 @@ def test_spmm_csell_tiny_and_degenerate_shapes():
                                      (np.float32, 50), (np.float64, 5), (np.float64, 12), (np.float64, 31)])
 def test_spmm_width_routing(dtype, B, monkeypatch):
     """Row-major operands: B <= 4 narrow kernel, 5 <= B (B * sizeof <= 256 bytes) the lane-per-row kernel (fp32) or the 2-D
-    kernel (fp64), wider the SELL kernel.
+    kernel (under SS_CSELL=0), wider the SELL kernel.
     Widths that cannot be staged in 16-byte pieces (B = 5, 7, 9, 31; a leading dimension that is no multiple of 16
     bytes) go through the padded copy of R; SS_COL=0 (SELL kernel) must agree to rounding; results are bitwise
     repeatable (fixed summation order)."""
@@ -654,7 +657,7 @@ def test_spmm_width_routing(dtype, B, monkeypatch):
     monkeypatch.setenv("SS_NARROW_CHUNK", "600")     # 5 chunks of R
     w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
     got = w.spmm(R.astype(dtype))
-    assert ("spmm_csell" if dtype == np.float32 else "spmm_colgroup") in ss.path_last()
+    assert "spmm_csell" in ss.path_last()
     assert_close_signed(got, want, dtype)
     assert np.array_equal(got, w.spmm(R.astype(dtype)))
     for b, name in ((4, "spmm_chunked_narrow"), (3, "spmm_chunked_narrow"), (80, "spmm_sell")):
