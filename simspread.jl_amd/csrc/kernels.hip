@@ -129,7 +129,10 @@ struct TransferArgs {
   int accumulate;  // add to what `out` already holds (dense regime: the feature path came from the GEMM)
   float xmax;      // FIX: largest |value| of the Mt operand
   int small_weighted;  // host only: weighted operand of at most 32 MiB (picks the default batch size)
+  int chunk_interleave;  // SS_TRANSFER_ORDER=0: rows take all their chunks in turn (the order of rounds 1-2)
 };
+template <class T>
+__device__ __forceinline__ bool getenv_chunk_interleave(const TransferArgs<T>& p) { return p.chunk_interleave != 0; }
 
 // One single-wave workgroup per (row r of L, column chunk c of T); c = blockIdx % nchunks so that,
 // with the dispatcher dealing workgroups round-robin over the 8 XCDs, chunk c is always served by
@@ -320,8 +323,21 @@ __global__ void __launch_bounds__(TRANSFER_THREADS) transfer_kernel(TransferArgs
   constexpr int NCOPY = DUAL ? 2 : 1;
   unsigned* bits = reinterpret_cast<unsigned*>(acc + NCOPY * astride);  // LOO only: source owns the dropped feature
   const int lane = threadIdx.x;
-  const int c = blockIdx.x % p.nchunks;
-  const int64_t r = blockIdx.x / p.nchunks;
+  // Workgroup i runs on XCD i % 8 and chunk c on XCD c % 8 (the chunk count is a multiple of 8).  With more than 8
+  // chunks the groups of 8 chunks are walked ONE AFTER THE OTHER over all rows (round 3; before: every row took all its
+  // chunks in turn): what the 8 XCDs re-read from row to row is then 8 chunk slices of X' instead of all of it -- at
+  // C3 200 MB instead of 600 MB, i.e. inside the 256 MB Infinity Cache instead of in HBM.  8 chunks (C2): same order as before.
+  int c;
+  int64_t r;
+  if (p.nchunks > 8 && p.nchunks % 8 == 0 && !getenv_chunk_interleave(p)) {
+    const int64_t nrows = (int64_t)gridDim.x / p.nchunks, per = nrows * 8;
+    const int64_t grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
+    r = rem >> 3;
+    c = (int)(grp * 8 + (rem & 7));
+  } else {
+    c = blockIdx.x % p.nchunks;
+    r = blockIdx.x / p.nchunks;
+  }
   const int64_t gr = p.row_ids ? (int64_t)p.row_ids[p.row_begin + r] : p.row_begin + r;
   const int64_t j0 = (int64_t)c * p.SC;
   const int jn = (int)((p.nj - j0 < p.SC) ? (p.nj - j0) : p.SC);
@@ -1247,6 +1263,7 @@ int launch_transfer(int nterms, const DevCsr<T>* L[2], const T* inv1[2], const D
     }
     p.small_weighted = (weighted && bytes <= (32LL << 20)) ? 1 : 0;
   }
+  p.chunk_interleave = (getenv("SS_TRANSFER_ORDER") && atoi(getenv("SS_TRANSFER_ORDER")) == 0) ? 1 : 0;
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
   bool binm = true;
@@ -1274,6 +1291,7 @@ int launch_transfer_loo(const DevCsr<T>& X, const DevChunked<T>& XT, const int* 
   p.nchunks = XT.nchunks;
   p.out = out;
   p.ld = ld;
+  p.chunk_interleave = (getenv("SS_TRANSFER_ORDER") && atoi(getenv("SS_TRANSFER_ORDER")) == 0) ? 1 : 0;
   const int64_t grid = nrows * p.nchunks;
   if (grid >= (1LL << 31)) return fail(SS_EUNSUPPORTED, "transfer grid too large; lower SS_TRANSFER_BYTES");
   const bool dual = transfer_dual();
