@@ -1038,6 +1038,24 @@ def test_tutorial_example_runs_end_to_end_on_the_device():
         assert out[weighted]["AuROC"] > 0.9 and out[weighted]["accuracy_of_predicted"] > 0.9   # iris is easy
 
 
+def test_stage1_chunk_group_order_is_bitwise_the_old_order(monkeypatch):
+    """Round 3: with more than 8 column chunks stage 1 walks the groups of 8 chunks one after the other over all rows
+    (working set of the XCDs' L2 / Infinity Cache) instead of giving every row all its chunks in turn.  Only the launch
+    order changes: query rows, source rows and leave-one-out rows must be bit-identical to SS_TRANSFER_ORDER=0, and right."""
+    Xq, Xs, Ys = O.synth_bipartite(131, 3000, 3000, 400, 0.04, 0.02, seed=8, dtype=np.float32)
+    monkeypatch.setenv("SS_TRANSFER_CHUNK", "100")          # 30 chunks -> 32: four groups of 8
+    res = {}
+    for order in ("1", "0"):
+        monkeypatch.setenv("SS_TRANSFER_ORDER", order)
+        g = ss.DeviceGraph.from_sparse(Xq, Xs, Ys, dtype=np.float32)
+        g3 = ss.DeviceGraph.from_sparse(None, Xs, Ys, dtype=np.float32)
+        res[order] = (g.predict("query").copy(), g.predict("source", 10, 300).copy(), g3.predict_loo(500, 900, clean=True).copy())
+        g.close(); g3.close()
+    for a, b in zip(res["1"], res["0"]):
+        assert np.array_equal(a, b)
+    assert_close(res["1"][0], O.predict_factored(*(m.astype(np.float64) for m in (Xq, Xs, Ys))), np.float32)
+
+
 # ----------------------------------------------------------------------------- stage-1 variants of round 3 (opt-in kernels)
 @pytest.mark.parametrize("variant", [
     {"SS_TRANSFER_V": "2", "SS_TRANSFER_FIX": "0"},                    # query-block workgroups, plain read-add-write
