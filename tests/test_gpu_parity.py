@@ -624,6 +624,21 @@ def test_spmm_csell_lane_per_row(B, dtype, binary, monkeypatch):
     assert_close_signed(other, want, dtype)
 
 
+def test_spmm_csell_falls_back_to_the_2d_kernel_when_the_operand_does_not_fit(monkeypatch):
+    """More than 2^24 (chunk, slice) blocks: csell_build declines (no error), the 2-D kernel serves the call."""
+    rng = np.random.default_rng(9)
+    M, K, nnz = 520_000, 40_000, 60_000
+    W = sp.csr_matrix((rng.random(nnz) + 0.5, (rng.integers(0, M, nnz), rng.integers(0, K, nnz))), shape=(M, K))
+    W.sum_duplicates()
+    R = rng.standard_normal((K, 8)).astype(np.float32)
+    monkeypatch.setenv("SS_NARROW_CHUNK", "16")          # 2500 chunks x 8125 slices
+    w = ss.DeviceSpMat(W.astype(np.float32), dtype=np.float32)
+    got = w.spmm(R)
+    assert "spmm_colgroup" in ss.path_last() and "spmm_csell" not in ss.path_last(), ss.path_last()
+    want = W @ R.astype(np.float64)
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
 def test_spmm_csell_tiny_and_degenerate_shapes():
     """One row, one column, an all-zero matrix, fewer rows than a slice, K smaller than a chunk."""
     rng = np.random.default_rng(5)
