@@ -794,8 +794,8 @@ __global__ void csell_desc_kernel(const int* __restrict__ base, const int* __res
 // One wave per block: writes the block's pairs in step order.  The order of a lane's entries is free; for tile rows
 // narrower than an LDS line (64 / 128 bytes: 4 / 2 tile rows per 256 bytes) it is scheduled position by position: the lanes
 // that read the same 16-byte slot number in the same LDS cycle (same lane & (pieces - 1) inside one of the four 16-lane
-// groups ds_read_b128 is served in) take tile rows of different classes (k mod 4 / k mod 2), largest remaining class first,
-// rotating priority; a lane with nothing else left takes a conflicting entry.
+// groups ds_read_b128 is served in) take tile rows of different classes (k mod 4 / k mod 2): most constrained lane first,
+// its largest remaining class; a lane with nothing else left takes a conflicting entry.
 template <class T, int ROWB>
 __global__ void __launch_bounds__(64) csell_fill_kernel(const int* __restrict__ ptr, const int* __restrict__ idx,
                                                         const T* __restrict__ val, int64_t rows, int KC, int nslices,
@@ -827,6 +827,9 @@ __global__ void __launch_bounds__(64) csell_fill_kernel(const int* __restrict__ 
       for (int q = 0; q < NCL; ++q) cur[lane][q] -= cnt[lane][q];
     }
     int left = n;
+    unsigned have = 0;   // classes this lane still has entries in
+    if (NCL > 1)
+      for (int q = 0; q < NCL; ++q) have |= (cnt[lane][q] > 0 ? 1u : 0u) << q;
     int64_t runp = 0;
     unsigned long long mask = 0ull;
     int rank = 0;
@@ -835,18 +838,29 @@ __global__ void __launch_bounds__(64) csell_fill_kernel(const int* __restrict__ 
       if (NCL == 1) {
         if (t < n) e = first + t;
       } else {
+        // most constrained lane first (the lane with the fewest classes that are still free for its slot number; ties: the
+        // longer rest), as in the SELL builder
         unsigned claimed = 0;
         int mine = -1;
-        for (int i = 0; i < 16; ++i) {
-          const int turn = (i + t) & 15;
-          const int chooser = b128_lane_of_group(grp, turn);
+        bool done = left == 0;
+        const int psh = (lane & (NPC - 1)) * NCL;
+        for (int it = 0; it < 16; ++it) {
+          if (__ballot(!done) == 0ull) break;
+          const int rest = left > 4095 ? 4095 : left;
+          int key = done ? 0x7fffffff : ((__popc(have & ~(claimed >> psh)) << 20) | ((4095 - rest) << 4) | gi);
+#pragma unroll
+          for (int m2 = 1; m2 < 16; m2 <<= 1) {
+            const int other = __shfl(key, b128_lane_of_group(grp, gi ^ m2));
+            key = other < key ? other : key;
+          }
+          const bool any = key != 0x7fffffff;
+          const int wl = b128_lane_of_group(grp, key & 15);
           int choice = -1;
-          if (gi == turn && left > 0) {
-            const int pid = lane & (NPC - 1);
+          if (any && !done && gi == (key & 15)) {
             int best = -1, bestc = 0;
             for (int q = 0; q < NCL; ++q) {
               const int cq = cnt[lane][q];
-              if (cq > bestc && !((claimed >> (pid * NCL + q)) & 1u)) { best = q; bestc = cq; }
+              if (cq > bestc && !((claimed >> (psh + q)) & 1u)) { best = q; bestc = cq; }
             }
             if (best < 0)
               for (int q = 0; q < NCL; ++q) {
@@ -855,14 +869,16 @@ __global__ void __launch_bounds__(64) csell_fill_kernel(const int* __restrict__ 
               }
             choice = best;
             mine = best;
+            done = true;
           }
-          const int ch = __shfl(choice, chooser);
-          if (ch >= 0) claimed |= 1u << ((chooser & (NPC - 1)) * NCL + ch);
+          const int ch = __shfl(choice, wl);
+          if (any && ch >= 0) claimed |= 1u << ((wl & (NPC - 1)) * NCL + ch);
         }
         if (mine >= 0) {
           e = perm[cur[lane][mine]];
           cur[lane][mine]++;
           cnt[lane][mine]--;
+          if (cnt[lane][mine] == 0) have &= ~(1u << mine);
           --left;
         }
       }
