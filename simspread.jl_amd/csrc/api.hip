@@ -833,15 +833,18 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
     // the lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip, round 3); SS_CSELL=0: the 2-D kernel
     bool done = false;
     if (!(getenv("SS_CSELL") && atoi(getenv("SS_CSELL")) == 0)) {
-      DevCsell<T>& cs = m.csell[slot];
-      if (!m.csell_tried[slot]) {
-        int kc = csell_chunk_cols(rowb);
+      // fp32 B <= 8: 32-byte tile rows (two pieces) instead of half-empty 64-byte ones
+      const bool half = sizeof(T) == 4 && B <= 8 && !(getenv("SS_CSELL_ROW32") && atoi(getenv("SS_CSELL_ROW32")) == 0);
+      const int crowb = half ? 32 : rowb, cslot = half ? 3 : slot, cbv = crowb / (int)sizeof(T);
+      DevCsell<T>& cs = m.csell[cslot];
+      if (!m.csell_tried[cslot]) {
+        int kc = csell_chunk_cols(crowb);
         if (const char* e = getenv("SS_NARROW_CHUNK")) {
           const int v = atoi(e);
           if (v >= 16 && v < kc) kc = v;
         }
-        SS_TRY(csell_build<T>(m.csr, kc, bv, cs));
-        m.csell_tried[slot] = true;
+        SS_TRY(csell_build<T>(m.csr, kc, cbv, cs));
+        m.csell_tried[cslot] = true;
       }
       if (cs.ok) {
         StageTimer t2(ST_SPMM);

@@ -578,7 +578,7 @@ def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
 
 
 @pytest.mark.parametrize("binary", [False, True])
-@pytest.mark.parametrize("B,dtype", [(5, np.float32), (12, np.float32), (16, np.float32), (17, np.float32), (28, np.float32),
+@pytest.mark.parametrize("B,dtype", [(5, np.float32), (8, np.float32), (12, np.float32), (16, np.float32), (17, np.float32), (28, np.float32),
                                      (32, np.float32), (33, np.float32), (52, np.float32), (64, np.float32),
                                      (5, np.float64), (8, np.float64), (9, np.float64), (16, np.float64), (23, np.float64),
                                      (32, np.float64)])
