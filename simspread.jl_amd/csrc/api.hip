@@ -810,7 +810,7 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
   hipEvent_t e_begin, e_end;
   SS_TRY(timing_mark(&e_begin));
   // Routing by width, row-major operands (measured at 100k x 100k / 1 %):
-  //   B <= 4                          narrow kernel: W streamed once, the chunk of R in LDS, lanes of a row folded -- the
+  //   B <= 4                          narrow kernel (fp32 B = 3, 4: spmm_csell.hip on 16-byte tile rows): W streamed once, the chunk of R in LDS, lanes of a row folded -- the
   //                                   HBM-bound regime (B = 1 0.13 ms = 4.6 TB/s of the 6 B/nnz operand)
   //   5 <= B, B*sizeof(T) <= 256 B    fp32: lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip; B = 8 / 16 / 32 / 64
   //                                   0.19 / 0.18 / 0.35 / 0.70 ms); fp64 (and SS_CSELL=0): 2-D kernel (spmm_colgroup.hip), tile rows
@@ -867,6 +867,20 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
       SS_TRY(launch_spmm_colgroup<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
       timing_count(ST_NSPMM, 1);
     }
+  } else if (narrow && B >= 3 && !(getenv("SS_CSELL_ROW16") && atoi(getenv("SS_CSELL_ROW16")) == 0) &&
+             !(getenv("SS_CSELL") && atoi(getenv("SS_CSELL")) == 0) &&
+             [&]() -> bool {   // B = 3, 4: the lane-per-row kernel with four columns per tile row (16 bytes in fp32: 0.136
+                               // vs 0.150 ms at B = 4; 32 bytes in fp64)
+               DevCsell<T>& cs = m.csell[4];
+               if (!m.csell_tried[4]) {
+                 if (csell_build<T>(m.csr, csell_chunk_cols(4 * (int)sizeof(T)), 4, cs) != SS_OK) return false;
+                 m.csell_tried[4] = true;
+               }
+               return cs.ok;
+             }()) {
+    StageTimer t2(ST_SPMM);
+    SS_TRY(launch_spmm_csell<T>(m.csell[4], Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
+    timing_count(ST_NSPMM, 1);
   } else if (narrow) {
     int slot = 0, bv = 1;
     while (bv < B) { bv <<= 1; ++slot; }

@@ -903,8 +903,8 @@ int csell_build(const DevCsr<T>& in, int KC, int QT, DevCsell<T>& out) {
   hipStream_t st = ctx().stream;
   if (KC < 1 || KC > 32767) return fail(SS_EINVAL, "compact sliced ELL: chunk size out of range");
   const int rowb = QT * (int)sizeof(T);
-  if (rowb != 32 && rowb != 64 && rowb != 128 && rowb != 256)
-    return fail(SS_EINVAL, "compact sliced ELL: tile rows must be 32, 64, 128 or 256 bytes");
+  if (rowb != 16 && rowb != 32 && rowb != 64 && rowb != 128 && rowb != 256)
+    return fail(SS_EINVAL, "compact sliced ELL: tile rows must be 16, 32, 64, 128 or 256 bytes");
   out.ok = false;
   out.rows = in.rows; out.cols = in.cols; out.nnz = in.nnz; out.binary = in.binary;
   out.KC = KC; out.QT = QT;
@@ -942,7 +942,10 @@ int csell_build(const DevCsr<T>& in, int KC, int QT, DevCsell<T>& out) {
   if (rowb < 256) SS_TRY(perm.alloc(in.nnz));
   unsigned short* p16 = reinterpret_cast<unsigned short*>(out.pidx.p);
   T* pv = in.binary ? (T*)nullptr : out.pval.p;
-  if (rowb == 32)
+  if (rowb == 16)
+    hipLaunchKernelGGL((csell_fill_kernel<T, 16>), dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
+                       out.nslices, nblocks, out.desc.p, perm.p, p16, pv);
+  else if (rowb == 32)
     hipLaunchKernelGGL((csell_fill_kernel<T, 32>), dim3(grid), dim3(64), 0, st, in.ptr.p, in.idx.p, in.val.p, in.rows, KC,
                        out.nslices, nblocks, out.desc.p, perm.p, p16, pv);
   else if (rowb == 64)

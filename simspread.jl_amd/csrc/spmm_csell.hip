@@ -61,8 +61,8 @@ __global__ void __launch_bounds__(CSELL_WAVES * 64) spmm_csell_kernel(CsArgs<T> 
   constexpr int PW = 16 / (int)sizeof(T);    // values per piece
   typedef T f4 __attribute__((ext_vector_type(PW)));   // one piece
   typedef T t2 __attribute__((ext_vector_type(2)));    // the two values of a pair
-  constexpr int NB = (ROWB == 128 || ROWB == 32) ? 2 : 4;   // LDS reads per batch: one batch in flight while the one before is multiplied
-  constexpr int RSH = ROWB == 256 ? 8 : (ROWB == 128 ? 7 : (ROWB == 64 ? 6 : 5));
+  constexpr int NB = (ROWB == 128 || ROWB <= 32) ? 2 : 4;   // LDS reads per batch: one batch in flight while the one before is multiplied
+  constexpr int RSH = ROWB == 256 ? 8 : (ROWB == 128 ? 7 : (ROWB == 64 ? 6 : (ROWB == 32 ? 5 : 4)));
   extern __shared__ __align__(16) unsigned char tb[];   // the tile [KC + 1][ROWB] at LDS offset 0 (no static LDS here)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -349,18 +349,20 @@ int launch_spmm_csell(const DevCsell<T>& W, const T* R, int64_t ldr, int B, T* F
 #define SS_CS(QTV) (W.binary ? launch_csell_variant<T, QTV, true>(a, (unsigned)grid, lds) : launch_csell_variant<T, QTV, false>(a, (unsigned)grid, lds))
   if constexpr (sizeof(T) == 4) {
     switch (QT) {
+      case 4: rc = SS_CS(4); break;
       case 8: rc = SS_CS(8); break;
       case 16: rc = SS_CS(16); break;
       case 32: rc = SS_CS(32); break;
       case 64: rc = SS_CS(64); break;
-      default: return fail(SS_EINVAL, "spmm_csell: tile width must be 8, 16, 32 or 64 (fp32)");
+      default: return fail(SS_EINVAL, "spmm_csell: tile width must be 4, 8, 16, 32 or 64 (fp32)");
     }
   } else {
     switch (QT) {
+      case 4: rc = SS_CS(4); break;
       case 8: rc = SS_CS(8); break;
       case 16: rc = SS_CS(16); break;
       case 32: rc = SS_CS(32); break;
-      default: return fail(SS_EINVAL, "spmm_csell: tile width must be 8, 16 or 32 (fp64)");
+      default: return fail(SS_EINVAL, "spmm_csell: tile width must be 4, 8, 16 or 32 (fp64)");
     }
   }
 #undef SS_CS
