@@ -867,6 +867,20 @@ static int spmm_impl(ss_spmat* h, const T* R, int64_t B, int64_t ldr, int r_layo
       SS_TRY(launch_spmm_colgroup<T>(op, bv, Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
       timing_count(ST_NSPMM, 1);
     }
+  } else if (narrow && sizeof(T) == 8 && B == 2 && !(getenv("SS_CSELL_B12") && atoi(getenv("SS_CSELL_B12")) == 0) &&
+             !(getenv("SS_CSELL") && atoi(getenv("SS_CSELL")) == 0) &&
+             [&]() -> bool {   // fp64 B = 2 on 16-byte tile rows: 0.199 vs 0.234 ms for the narrow kernel (measured also: fp64
+                               // B = 1 0.204 vs 0.200, fp32 B = 1 / 2 0.138 / 0.139 vs 0.112 / 0.116 -- those stay narrow)
+               DevCsell<T>& cs = m.csell[5];
+               if (!m.csell_tried[5]) {
+                 if (csell_build<T>(m.csr, csell_chunk_cols(16), 16 / (int)sizeof(T), cs) != SS_OK) return false;
+                 m.csell_tried[5] = true;
+               }
+               return cs.ok;
+             }()) {
+    StageTimer t2(ST_SPMM);
+    SS_TRY(launch_spmm_csell<T>(m.csell[5], Rd, ldr_d, (int)B, Fd, ldf_d, m.partial));
+    timing_count(ST_NSPMM, 1);
   } else if (narrow && B >= 3 && !(getenv("SS_CSELL_ROW16") && atoi(getenv("SS_CSELL_ROW16")) == 0) &&
              !(getenv("SS_CSELL") && atoi(getenv("SS_CSELL")) == 0) &&
              [&]() -> bool {   // B = 3, 4: the lane-per-row kernel with four columns per tile row (16 bytes in fp32: 0.136

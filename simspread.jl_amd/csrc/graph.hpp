@@ -130,8 +130,8 @@ struct SpMat {
   int sell_qt = 0;
   DevChunked<T> narrow[3];  // quad-aligned chunked operands of the narrow kernel for B <= 1, 2, 4 (built lazily)
   DevChunked<T> col[3];     // operands of the 2-D kernel: 64-, 128- and 256-byte tile rows (built lazily)
-  DevCsell<T> csell[5];     // operands of the lane-per-row kernel for 64-, 128-, 256- and (fp32, B <= 8) 32-byte tile rows (built lazily)
-  bool csell_tried[5] = {false, false, false, false, false};
+  DevCsell<T> csell[6];     // operands of the lane-per-row kernel for 64-, 128-, 256- and (fp32, B <= 8) 32-byte tile rows (built lazily)
+  bool csell_tried[6] = {false, false, false, false, false, false};
   DevBuf<T> partial;        // partial sums of the narrow / 2-D kernels (and the padded copy of R, spmm_colgroup.hip)
 };
 

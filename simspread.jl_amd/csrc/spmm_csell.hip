@@ -358,11 +358,12 @@ int launch_spmm_csell(const DevCsell<T>& W, const T* R, int64_t ldr, int B, T* F
     }
   } else {
     switch (QT) {
+      case 2: rc = SS_CS(2); break;
       case 4: rc = SS_CS(4); break;
       case 8: rc = SS_CS(8); break;
       case 16: rc = SS_CS(16); break;
       case 32: rc = SS_CS(32); break;
-      default: return fail(SS_EINVAL, "spmm_csell: tile width must be 4, 8, 16 or 32 (fp64)");
+      default: return fail(SS_EINVAL, "spmm_csell: tile width must be 2, 4, 8, 16 or 32 (fp64)");
     }
   }
 #undef SS_CS

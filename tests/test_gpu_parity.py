@@ -542,7 +542,7 @@ def test_spmm_narrow_every_group_size(mean_entries, dtype):
     for B in (1, 2, 3, 4):
         assert_close_signed(w.spmm(R[:, :B].astype(dtype)), W @ R[:, :B], dtype)
         # (B = 3, 4 went to the lane-per-row kernel with four columns per tile row in round 3; SS_CSELL_ROW16=0 keeps them here)
-        assert ("spmm_csell" if B >= 3 else "spmm_chunked_narrow") in ss.path_last()
+        assert ("spmm_csell" if (B >= 3 or (B == 2 and dtype == np.float64)) else "spmm_chunked_narrow") in ss.path_last()
 
 
 @pytest.mark.parametrize("binary", [False, True])
@@ -581,7 +581,7 @@ def test_spmm_colgroup_2d_cut(dtype, B, binary, monkeypatch):
 @pytest.mark.parametrize("binary", [False, True])
 @pytest.mark.parametrize("B,dtype", [(3, np.float32), (4, np.float32), (5, np.float32), (8, np.float32), (12, np.float32), (16, np.float32), (17, np.float32), (28, np.float32),
                                      (32, np.float32), (33, np.float32), (52, np.float32), (64, np.float32),
-                                     (3, np.float64), (4, np.float64), (5, np.float64), (8, np.float64), (9, np.float64), (16, np.float64), (23, np.float64),
+                                     (2, np.float64), (3, np.float64), (4, np.float64), (5, np.float64), (8, np.float64), (9, np.float64), (16, np.float64), (23, np.float64),
                                      (32, np.float64)])
 def test_spmm_csell_lane_per_row(B, dtype, binary, monkeypatch):
     """Mid width since round 3 (fp32 B <= 64, fp64 B <= 32): the lane-per-row kernel on the compact sliced-ELL operand (spmm_csell.hip,
@@ -644,11 +644,12 @@ def test_spmm_csell_falls_back_to_the_2d_kernel_when_the_operand_does_not_fit(mo
 def test_spmm_narrow_kernel_still_serves_b3_b4_when_asked(dtype, monkeypatch):
     """SS_CSELL_ROW16=0: the narrow kernel at B = 3, 4 (by default they run on the lane-per-row kernel since round 3)."""
     monkeypatch.setenv("SS_CSELL_ROW16", "0")
+    monkeypatch.setenv("SS_CSELL_B12", "0")
     rng = np.random.default_rng(4)
     W = sp.random(2111, 5000, density=0.01, format="csr", random_state=rng, dtype=np.float64)
     W.data = rng.random(W.nnz) + 0.5
     w = ss.DeviceSpMat(W.astype(dtype), dtype=dtype)
-    for B in (3, 4):
+    for B in (2, 3, 4):
         R = rng.standard_normal((5000, B))
         assert_close_signed(w.spmm(R.astype(dtype)), W @ R, dtype)
         assert "spmm_chunked_narrow" in ss.path_last()
@@ -690,7 +691,7 @@ def test_spmm_width_routing(dtype, B, monkeypatch):
     assert "spmm_csell" in ss.path_last()
     assert_close_signed(got, want, dtype)
     assert np.array_equal(got, w.spmm(R.astype(dtype)))
-    for b, name in ((4, "spmm_csell"), (2, "spmm_chunked_narrow"), (80, "spmm_sell")):
+    for b, name in ((4, "spmm_csell"), (1, "spmm_chunked_narrow"), (80, "spmm_sell")):
         Rb = rng.standard_normal((K, b))
         assert_close_signed(w.spmm(Rb.astype(dtype)), W @ Rb, dtype)
         assert any(name in k for k in ss.path_last())
