@@ -420,8 +420,10 @@ __global__ void sell_width_kernel(const int* __restrict__ ptr, const int* __rest
     n = a - first;
   }
   for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(n, o); n = t > n ? t : n; }
-  // in quads, rounded up to whole groups of four: the SpMM kernel fetches and consumes four quads at a time
-  if (lane == 0) widthq[wave] = (((n + 3) >> 2) + 3) & ~3;
+  // in quads.  (Rounds 1-2 rounded up to whole groups of four quads because the SpMM kernel consumed four at a time;
+  // since round 3 its last group is consumed quad by quad: ~6 entries fewer per slice and chunk at C2 / C3, and the short
+  // rows of a power-law operand no longer cost 16 slots per chunk.)
+  if (lane == 0) widthq[wave] = (n + 3) >> 2;
 }
 
 template <class T>
@@ -658,8 +660,8 @@ int sell_build(const DevCsr<T>& in, int KCmax, DevSell<T>& out, int qt) {
   // padded storage well above nnz means skewed row lengths inside slices: split the longest rows into
   // virtual rows of bounded length and sort all (virtual) rows by length before cutting slices
   const char* force = getenv("SS_SELL_SORT");
-  // (the rounding of every slice to whole groups of four quads adds ~1.5 quads per slice and is not skew)
-  const bool want_sort = force ? atoi(force) != 0 : (((double)nq - 1.5 * (double)nws) * 256.0 > 1.3 * (double)in.nnz + 65536.0);
+  // (the rounding of every slice to whole quads adds ~0.4 quads per slice and is not skew)
+  const bool want_sort = force ? atoi(force) != 0 : (((double)nq - 0.4 * (double)nws) * 256.0 > 1.3 * (double)in.nnz + 65536.0);
   if (want_sort && in.rows > 64) {
     int64_t lmax = in.nnz / 4096;  // a slice of full-length virtual rows is ~1/4 of one wave's share of a workgroup
     if (const char* e = getenv("SS_SELL_LMAX")) lmax = atoll(e);

@@ -1440,7 +1440,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
           if (!BIN) wq[j] = vp[(int64_t)(base + j) * 64];
         }
       };
-      auto gather = [&](const uint2 (&iq)[NBQ], const Vec<T, 4> (&wq)[NBQ]) __attribute__((always_inline)) {
+      auto gather = [&](const uint2 (&iq)[NBQ], const Vec<T, 4> (&wq)[NBQ], int cnt) __attribute__((always_inline)) {
         // LDS address of tile[k] = k * 16: one SDWA shift per 16-bit index, used as the address itself (the tile
         // is the only LDS object of this kernel and starts at LDS address 0 -- checked once at kernel entry;
         // going through the generic tile pointer costs one more VALU add per non-zero)
@@ -1465,6 +1465,7 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
         };
 #pragma unroll
         for (int j = 0; j < NBQ; ++j) {
+          if (j >= cnt) break;   // wave-uniform; cnt == NBQ inside the loop (folds away), smaller only for a slice's tail
           const V t0 = row(half_shl<0>(iq[j].x, TSH));
           const V t1 = row(half_shl<1>(iq[j].x, TSH));
           const V t2 = row(half_shl<0>(iq[j].y, TSH));
@@ -1490,15 +1491,24 @@ __global__ void __launch_bounds__(SELL_THREADS) spmm_sell_kernel(SellArgs<T> a) 
       // Measured and not kept (round 3): a third register set (two groups of quads in flight while one is gathered; the
       // gathers split in two by a compiler barrier so that it fits in 123 registers): 0.605 vs 0.594 ms at C2, 12.8 vs
       // 12.6 ms at C3 -- the index stream is bound by the bytes through the CU's vector-memory path, not by its latency.
+      //
+      // Two register sets, both requested before the first gather; a slice is a whole number of QUADS (not of groups, since
+      // round 3): the last one or two groups are consumed quad by quad under wave-uniform conditions, outside the loop.
+      // Requests run up to two groups past the slice (the next slice, or the slack behind the last one).
       fetch(ia, wa, 0);
+      fetch(ib, wb, NBQ);
       int u = 0;
       for (; u + 2 * NBQ <= nq; u += 2 * NBQ) {
-        fetch(ib, wb, u + NBQ);
-        gather(ia, wa);
+        gather(ia, wa, NBQ);
         fetch(ia, wa, u + 2 * NBQ);
-        gather(ib, wb);
+        gather(ib, wb, NBQ);
+        fetch(ib, wb, u + 3 * NBQ);
       }
-      if (u < nq) gather(ia, wa);  // odd number of groups: the last one is already here
+      {
+        const int rest = nq - u;   // 0 .. 2 * NBQ - 1 quads; ia holds quads u .., ib quads u + NBQ ..
+        if (rest > 0) gather(ia, wa, rest < NBQ ? rest : NBQ);
+        if (rest > NBQ) gather(ib, wb, rest - NBQ);
+      }
       if (m < a.M) {
         const bool flag = last && a.clean_deg != nullptr && a.clean_deg[m] == 0;
 #pragma unroll
